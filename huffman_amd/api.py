@@ -1,0 +1,441 @@
+"""Host-side mirror of the reference's module boundaries over the C ABI.
+
+Class names, constructor parameters and port names follow the Chisel modules
+(src/main/scala/huffman/encoder/*.scala, decoder/top_decoder.scala); each class is a thin
+wrapper around one entry point of libhuffhip.so.  PyTorch is used only for device memory and
+streams.  Nothing here computes on the CPU and nothing falls back to it: every call goes
+through the HIP library or raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from ._lib import (HF_CHUNK_SYMS, HF_CODEBOOK_DEV_BYTES, HF_LAYOUT_BF16_EXP, HF_LAYOUT_FP8,
+                   HF_LAYOUT_U8, HF_MODE_AUTO, HF_MODE_BYPASS, HF_MODE_HUFFMAN, HuffhipError,
+                   check, hf_entropy_config)
+
+_u8p, _u16p, _u32p, _u64p = (C.POINTER(C.c_uint8), C.POINTER(C.c_uint16), C.POINTER(C.c_uint32),
+                             C.POINTER(C.c_uint64))
+
+
+def _np(a, dt) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=dt))
+
+
+def _ptr(a: np.ndarray, t):
+    return a.ctypes.data_as(t)
+
+
+def layout_of(t: torch.Tensor) -> int:
+    """bf16 tensors are coded by exponent byte, 8-bit tensors byte by byte."""
+    if t.dtype == torch.bfloat16:
+        return HF_LAYOUT_BF16_EXP
+    if t.dtype in (torch.uint8, torch.int8):
+        return HF_LAYOUT_U8
+    if t.dtype in (getattr(torch, "float8_e4m3fn", None), getattr(torch, "float8_e5m2", None)):
+        return HF_LAYOUT_FP8
+    raise TypeError(f"unsupported element type {t.dtype}")
+
+
+def _dev_ptr(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+class Context:
+    """One hf_ctx: a device plus the stream all of its launches go to."""
+
+    def __init__(self, device: Optional[int] = None, stream: Optional[torch.cuda.Stream] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("huffman_amd needs a GPU: no HIP device is visible")
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        with torch.cuda.device(self.device):
+            self.stream = stream if stream is not None else torch.cuda.current_stream()
+        h = C.c_void_p()
+        check(L.lib().hf_ctx_create(C.byref(h), self.device, C.c_void_p(self.stream.cuda_stream)),
+              "hf_ctx_create")
+        self._h = h
+
+    @property
+    def handle(self):
+        return self._h
+
+    def flush(self) -> None:
+        check(L.lib().hf_flush(self._h), "hf_flush")
+
+    def sync(self) -> None:
+        check(L.lib().hf_sync(self._h), "hf_sync")
+
+    def set_timing(self, on: bool) -> None:
+        check(L.lib().hf_set_timing(self._h, 1 if on else 0), "hf_set_timing")
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float(0)
+        check(L.lib().hf_last_kernel_ms(self._h, C.byref(ms)), "hf_last_kernel_ms")
+        return float(ms.value)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            L.lib().hf_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx: dict = {}
+
+
+def default_context() -> Context:
+    dev = torch.cuda.current_device()
+    key = (dev, torch.cuda.current_stream().cuda_stream)
+    if key not in _default_ctx:
+        _default_ctx[key] = Context(dev)
+    return _default_ctx[key]
+
+
+class _Module:
+    def __init__(self, ctx: Optional[Context]):
+        self._ctx = ctx
+
+    @property
+    def ctx(self) -> Context:
+        if self._ctx is None:
+            self._ctx = default_context()
+        return self._ctx
+
+    def flush(self) -> None:
+        """`flush` port: abort the block in flight and clear state."""
+        self.ctx.flush()
+
+
+# ---------------------------------------------------------------------------------------------
+class SymbolStat(_Module):
+    """symbol_stat.scala:6-58.  ``freq_out`` of one block of symbols."""
+
+    def __init__(self, sym_width: int = 8, wtWidth: int = 32, depth: int = 256, ctx=None):
+        super().__init__(ctx)
+        self.sym_width, self.wtWidth, self.depth = sym_width, wtWidth, depth
+
+    def __call__(self, data_in: torch.Tensor, layout: Optional[int] = None) -> np.ndarray:
+        lay = layout_of(data_in) if layout is None else layout
+        freq = np.zeros(self.depth, np.uint64)
+        check(L.lib().hf_symbol_stat(self.ctx.handle, C.c_void_p(_dev_ptr(data_in)),
+                                     data_in.numel(), lay, self.depth, self.wtWidth,
+                                     _ptr(freq, _u64p)), "hf_symbol_stat")
+        return freq
+
+    def accumulate(self, data_in: torch.Tensor, freq256: torch.Tensor,
+                   layout: Optional[int] = None) -> None:
+        """Device-side block: add the counts of ``data_in`` into ``freq256`` (int64[256])."""
+        lay = layout_of(data_in) if layout is None else layout
+        assert freq256.dtype == torch.int64 and freq256.numel() == 256 and freq256.is_cuda
+        check(L.lib().hf_symbol_stat_dev(self.ctx.handle, C.c_void_p(_dev_ptr(data_in)),
+                                         data_in.numel(), lay, C.c_void_p(freq256.data_ptr())),
+              "hf_symbol_stat_dev")
+
+
+class SymbolSort(_Module):
+    """symbol_sort.scala:82-148.  ``sorted_out`` plus the symbol identities."""
+
+    def __init__(self, depth: int = 256, wtWidth: int = 32, ctx=None):
+        super().__init__(ctx)
+        self.depth, self.wtWidth = depth, wtWidth
+        self.rank2sym: Optional[np.ndarray] = None
+
+    def __call__(self, freq_in) -> np.ndarray:
+        f = _np(freq_in, np.uint64)
+        assert f.size == self.depth
+        out = np.zeros(self.depth, np.uint64)
+        ids = np.zeros(self.depth, np.uint16)
+        check(L.lib().hf_symbol_sort(self.ctx.handle, _ptr(f, _u64p), self.depth,
+                                     _ptr(out, _u64p), _ptr(ids, _u16p)), "hf_symbol_sort")
+        self.rank2sym = ids
+        return out
+
+
+class ShannonEntropy(_Module):
+    """shannon_entropy.scala:11-118 with adaptive_threshold.scala:11-87 inside."""
+
+    def __init__(self, depth: int = 256, wtWidth: int = 32, ctx=None):
+        super().__init__(ctx)
+        self.depth, self.wtWidth = depth, wtWidth
+
+    def __call__(self, freq_in):
+        f = _np(freq_in, np.uint64)
+        assert f.size == self.depth
+        e = C.c_uint32(0)
+        m = C.c_int(0)
+        check(L.lib().hf_entropy(self.ctx.handle, _ptr(f, _u64p), self.depth, C.byref(e),
+                                 C.byref(m)), "hf_entropy")
+        return int(e.value), int(m.value)  # entropy_out, compression_mode
+
+
+class HuffmanTreeBuilder(_Module):
+    """tree_build.scala:17-140."""
+
+    def __init__(self, numLeaves: int = 256, wtWidth: int = 32, ctx=None):
+        super().__init__(ctx)
+        self.numLeaves, self.wtWidth = numLeaves, wtWidth
+
+    def __call__(self, freqs) -> dict:
+        f = _np(freqs, np.uint64)
+        N = self.numLeaves
+        assert f.size == N
+        M = 2 * N - 1
+        weights = np.zeros(M, np.uint64)
+        lefts = np.zeros(M, np.uint16)
+        rights = np.zeros(M, np.uint16)
+        depths = np.zeros(N, np.uint16)
+        root = C.c_uint16(0)
+        W = 32 if self.wtWidth <= 32 else 64
+        check(L.lib().hf_tree_build(self.ctx.handle, _ptr(f, _u64p), N, W, _ptr(weights, _u64p),
+                                    _ptr(lefts, _u16p), _ptr(rights, _u16p), C.byref(root),
+                                    _ptr(depths, _u16p)), "hf_tree_build")
+        return dict(root=int(root.value), weights=weights, lefts=lefts, rights=rights,
+                    depths=depths)
+
+
+class tree_adjust(_Module):  # noqa: N801  (name as in tree_adjust.scala:6)
+    """tree_adjust.scala:6-127."""
+
+    def __init__(self, numLeaves: int = 256, maxDepth: int = 16, ctx=None):
+        super().__init__(ctx)
+        self.numLeaves, self.maxDepth = numLeaves, maxDepth
+
+    def __call__(self, depths_in) -> np.ndarray:
+        d = _np(depths_in, np.uint16)
+        assert d.size == self.numLeaves
+        out = np.zeros(self.numLeaves, np.uint16)
+        check(L.lib().hf_tree_adjust(self.ctx.handle, _ptr(d, _u16p), self.numLeaves,
+                                     self.maxDepth, _ptr(out, _u16p)), "hf_tree_adjust")
+        return out
+
+
+class EntropyAwareTreeBuilder(_Module):
+    """entropy_aware_tree_builder.scala:6-169: ``freq_in`` -> ``code_out``, ``length_out``."""
+
+    def __init__(self, depth: int = 256, wtWidth: int = 32, ctx=None):
+        super().__init__(ctx)
+        self.depth, self.wtWidth = depth, wtWidth
+
+    def __call__(self, freq_in, encoding_mode: int = 1, tree_depth_limit: int = 0,
+                 min_freq_threshold: int = 0):
+        f = _np(freq_in, np.uint64)
+        assert f.size == self.depth
+        cfg = hf_entropy_config(encoding_mode, tree_depth_limit, min_freq_threshold)
+        code = np.zeros(self.depth, np.uint16)
+        lens = np.zeros(self.depth, np.uint8)
+        check(L.lib().hf_codebook(self.ctx.handle, _ptr(f, _u64p), self.depth, C.byref(cfg),
+                                  _ptr(code, _u16p), _ptr(lens, _u8p)), "hf_codebook")
+        return code, lens
+
+
+class TreeQualityAnalyzer(_Module):
+    """tree_q_analyser.scala:10-47: (avg_length Q8, efficiency, compression_ratio)."""
+
+    def __init__(self, depth: int = 256, wtWidth: int = 32, ctx=None):
+        super().__init__(ctx)
+        self.depth, self.wtWidth = depth, wtWidth
+
+    def __call__(self, freq_in, code_length):
+        f = _np(freq_in, np.uint64)
+        l = _np(code_length, np.uint8)
+        a, e, r = C.c_uint16(0), C.c_uint16(0), C.c_uint16(0)
+        h = self._ctx.handle if self._ctx is not None else None
+        check(L.lib().hf_quality(h, _ptr(f, _u64p), _ptr(l, _u8p), self.depth, self.wtWidth,
+                                 C.byref(a), C.byref(e), C.byref(r)), "hf_quality")
+        return int(a.value), int(e.value), int(r.value)
+
+
+class DeviceCodebook:
+    """A codebook resident in device memory (encoder table + decoder lookup tables)."""
+
+    def __init__(self, ctx: Context, buf: Optional[torch.Tensor] = None):
+        self.ctx = ctx
+        self.buf = buf if buf is not None else torch.zeros(
+            HF_CODEBOOK_DEV_BYTES, dtype=torch.uint8, device=f"cuda:{ctx.device}")
+
+    @property
+    def ptr(self) -> int:
+        return self.buf.data_ptr()
+
+    def download(self):
+        code = np.zeros(256, np.uint16)
+        lens = np.zeros(256, np.uint8)
+        mode = C.c_int(0)
+        ent = C.c_uint32(0)
+        check(L.lib().hf_codebook_download(self.ctx.handle, C.c_void_p(self.ptr),
+                                           _ptr(code, _u16p), _ptr(lens, _u8p), C.byref(mode),
+                                           C.byref(ent)), "hf_codebook_download")
+        return code, lens, int(mode.value), int(ent.value)
+
+
+class MemWrapper(_Module):
+    """mem_wrapper.scala:6-87: the codebook RAM (write port, read port, bulk read, valid bits);
+    ``to_device`` places the table where the encoder and decoder kernels read it."""
+
+    def __init__(self, depth: int = 256, maxCodeLen: int = 16, addrWidth: int = 8, ctx=None):
+        super().__init__(ctx)
+        self.depth, self.maxCodeLen, self.addrWidth = depth, maxCodeLen, addrWidth
+        self._code = np.zeros(depth, np.uint16)
+        self._len = np.zeros(depth, np.uint8)
+        self._valid = np.zeros(depth, bool)
+
+    def write(self, write_addr: int, write_code: int, write_length: int) -> None:
+        self._code[write_addr] = write_code
+        self._len[write_addr] = write_length
+        self._valid[write_addr] = True
+
+    def read(self, read_addr: int):
+        return int(self._code[read_addr]), int(self._len[read_addr]), bool(self._valid[read_addr])
+
+    def bulk_read(self):
+        """code_table, length_table, table_ready (all entries written)."""
+        return self._code.copy(), self._len.copy(), bool(self._valid.all())
+
+    def flush(self) -> None:
+        self._valid[:] = False
+
+    def to_device(self, mode: int = HF_MODE_HUFFMAN) -> DeviceCodebook:
+        if self.depth != 256 or not self._valid.all():
+            raise ValueError("table_ready is low: write all 256 entries first")
+        cb = DeviceCodebook(self.ctx)
+        check(L.lib().hf_codebook_upload(self.ctx.handle, _ptr(self._code, _u16p),
+                                         _ptr(self._len, _u8p), mode, C.c_void_p(cb.ptr)),
+              "hf_codebook_upload")
+        return cb
+
+
+@dataclass
+class EncodedStream:
+    """What the encoder leaves in device memory for one tensor."""
+    n: int
+    layout: int
+    dtype: torch.dtype
+    payload: torch.Tensor      # int32 words (capacity may exceed total_words)
+    chunk_off: torch.Tensor    # int32[nchunks + 1]
+    side: Optional[torch.Tensor]  # uint8[n] for bf16, else None
+    codebook: DeviceCodebook
+    total_words: Optional[int] = None
+
+    @property
+    def nchunks(self) -> int:
+        return (self.n + HF_CHUNK_SYMS - 1) // HF_CHUNK_SYMS
+
+    def compressed_bytes(self) -> int:
+        """payload + side stream + chunk offsets + codebook as 256 x (16-bit code, 8-bit len)."""
+        assert self.total_words is not None
+        side = self.n if self.side is not None else 0
+        return 4 * self.total_words + side + 4 * (self.nchunks + 1) + 256 * 3
+
+    def ratio(self) -> float:
+        raw = self.n * (2 if self.layout == HF_LAYOUT_BF16_EXP else 1)
+        return raw / max(1, self.compressed_bytes())
+
+
+class EntropyAwareHuffmanSystem(_Module):
+    """top_encoder.scala:6-184: data_in -> encoded_out, with the bit packer behind it.
+
+    ``encode`` runs the whole pipeline on the device: SymbolStat -> SymbolSort ->
+    ShannonEntropy decision -> EntropyAwareTreeBuilder -> lookup + packing.
+    """
+
+    def __init__(self, symWidth: int = 8, wtWidth: int = 32, depth: int = 256,
+                 maxCodeLen: int = 16, ctx=None):
+        super().__init__(ctx)
+        if depth != 256 or symWidth != 8 or maxCodeLen != 16:
+            raise ValueError("the packed stream is defined for symWidth=8, depth=256, maxCodeLen=16")
+        self.symWidth, self.wtWidth, self.depth, self.maxCodeLen = symWidth, wtWidth, depth, maxCodeLen
+
+    # -- stages --------------------------------------------------------------------------------
+    def histogram(self, data_in: torch.Tensor, layout: Optional[int] = None,
+                  freq256: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if freq256 is None:
+            freq256 = torch.zeros(256, dtype=torch.int64, device=data_in.device)
+        SymbolStat(ctx=self.ctx).accumulate(data_in, freq256, layout)
+        return freq256
+
+    def codebook(self, freq256: torch.Tensor, mode: int = HF_MODE_AUTO,
+                 min_freq_threshold: int = 0,
+                 out: Optional[DeviceCodebook] = None) -> DeviceCodebook:
+        cb = out if out is not None else DeviceCodebook(self.ctx)
+        check(L.lib().hf_system_codebook_dev(self.ctx.handle, C.c_void_p(freq256.data_ptr()), mode,
+                                             min_freq_threshold, C.c_void_p(cb.ptr)),
+              "hf_system_codebook_dev")
+        return cb
+
+    def encode_with(self, data_in: torch.Tensor, cb: DeviceCodebook, layout: Optional[int] = None,
+                    payload: Optional[torch.Tensor] = None, side: Optional[torch.Tensor] = None,
+                    chunk_off: Optional[torch.Tensor] = None, sync: bool = True) -> EncodedStream:
+        lay = layout_of(data_in) if layout is None else layout
+        n = data_in.numel()
+        dev = data_in.device
+        nch = (n + HF_CHUNK_SYMS - 1) // HF_CHUNK_SYMS
+        if payload is None:
+            # room for 8 bits/symbol plus the per-lane look-ahead words; worst case is larger
+            # (hf_payload_bound_words) and is reported as HF_ERR_OVERFLOW, never overrun
+            payload = torch.empty(max(4, n // 4 + nch * 192 + 64), dtype=torch.int32, device=dev)
+        if chunk_off is None:
+            chunk_off = torch.empty(((nch + 1 + 3) // 4) * 4, dtype=torch.int32, device=dev)
+        if lay == HF_LAYOUT_BF16_EXP and side is None:
+            side = torch.empty(max(16, n), dtype=torch.uint8, device=dev)
+        total = C.c_uint64(0)
+        check(L.lib().hf_encode(self.ctx.handle, C.c_void_p(_dev_ptr(data_in)), n, lay,
+                                C.c_void_p(cb.ptr), C.c_void_p(_dev_ptr(side)),
+                                C.c_void_p(payload.data_ptr()), payload.numel(),
+                                C.c_void_p(chunk_off.data_ptr()),
+                                C.byref(total) if sync else None), "hf_encode")
+        return EncodedStream(n=n, layout=lay, dtype=data_in.dtype, payload=payload,
+                             chunk_off=chunk_off, side=side if lay == HF_LAYOUT_BF16_EXP else None,
+                             codebook=cb, total_words=int(total.value) if sync else None)
+
+    # -- whole path ----------------------------------------------------------------------------
+    def encode(self, data_in: torch.Tensor, mode: int = HF_MODE_AUTO,
+               layout: Optional[int] = None, min_freq_threshold: int = 0) -> EncodedStream:
+        data_in = data_in.contiguous()
+        freq = self.histogram(data_in, layout)
+        cb = self.codebook(freq, mode, min_freq_threshold)
+        return self.encode_with(data_in, cb, layout)
+
+    def encode_pairs(self, data_in: torch.Tensor, cb: DeviceCodebook,
+                     layout: Optional[int] = None) -> np.ndarray:
+        """``encoded_out`` beats, one per symbol: columns code, length, compression_mode."""
+        lay = layout_of(data_in) if layout is None else layout
+        n = data_in.numel()
+        beats = torch.empty(max(1, n), dtype=torch.int32, device=data_in.device)
+        check(L.lib().hf_encode_pairs(self.ctx.handle, C.c_void_p(_dev_ptr(data_in)), n, lay,
+                                      C.c_void_p(cb.ptr), C.c_void_p(beats.data_ptr())),
+              "hf_encode_pairs")
+        self.ctx.sync()
+        raw = beats[:n].cpu().numpy().view(np.uint32)
+        return np.stack([raw & 0xFFFF, (raw >> 16) & 0xFF, raw >> 24], axis=1).astype(np.uint32)
+
+
+class ParrallelHuffmanDecoder(_Module):  # spelling as in decoder/top_decoder.scala:6
+    """decoder/top_decoder.scala:6-10 (constructor only in the reference)."""
+
+    def __init__(self, symWidth: int = 8, wtWidth: int = 32, depth: int = 256,
+                 maxCodeLen: int = 16, ctx=None):
+        super().__init__(ctx)
+        if depth != 256 or symWidth != 8 or maxCodeLen != 16:
+            raise ValueError("the packed stream is defined for symWidth=8, depth=256, maxCodeLen=16")
+
+    def decode(self, s: EncodedStream, out: Optional[torch.Tensor] = None,
+               check_stream: bool = True) -> torch.Tensor:
+        if out is None:
+            out = torch.empty(max(s.n, 16), dtype=s.dtype, device=s.payload.device)
+        check(L.lib().hf_decode(self.ctx.handle, C.c_void_p(s.payload.data_ptr()),
+                                s.payload.numel(), C.c_void_p(s.chunk_off.data_ptr()),
+                                C.c_void_p(_dev_ptr(s.side)), s.n, s.layout,
+                                C.c_void_p(s.codebook.ptr), C.c_void_p(out.data_ptr()),
+                                1 if check_stream else 0), "hf_decode")
+        return out[:s.n]

@@ -1,0 +1,514 @@
+// C ABI of libhuffhip.so (declarations and reference citations: include/huffhip.h).
+// Host side only: argument checks, the per-context workspace, stream-ordered launches.
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+
+#include "hf_common.h"
+
+struct hf_ctx {
+    int device;
+    hipStream_t stream;
+    int num_cu;
+    hf_stage_io* d_io;
+    hf_stage_io* h_io;  // pinned
+    hf_cb_dev* d_cb;    // scratch codebook for hf_codebook_download staging
+    hf_cb_dev* h_cb;    // pinned
+    unsigned long long* d_freq;
+    unsigned long long* h_freq;  // pinned
+    unsigned long long* d_desc;
+    size_t desc_cap;    // entries
+    uint32_t* d_ctl;    // [0] ticket, [1] error bits; 64-byte block
+    uint32_t* h_ctl;    // pinned, 16 words
+    uint32_t* d_spill;
+    hipEvent_t ev0, ev1;
+    int timing;
+    int timed;
+    int last_hip;
+};
+
+namespace {
+
+#define HF_HIP(expr)                                   \
+    do {                                               \
+        hipError_t e_ = (expr);                        \
+        if (e_ != hipSuccess) {                        \
+            ctx->last_hip = (int)e_;                   \
+            return HF_ERR_HIP;                         \
+        }                                              \
+    } while (0)
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+inline bool layout_ok(int l) {
+    return l == HF_LAYOUT_U8 || l == HF_LAYOUT_BF16_EXP || l == HF_LAYOUT_FP8;
+}
+inline int norm_layout(int l) { return l == HF_LAYOUT_FP8 ? HF_LAYOUT_U8 : l; }
+inline uint64_t mask_w(int W) { return W >= 64 ? ~0ull : ((1ull << W) - 1ull); }
+inline int log2ceil_i(int x) {
+    int b = 0;
+    while ((1 << b) < x) ++b;
+    return b;
+}
+
+int kerr_to_code(uint32_t bits) {
+    if (bits & HF_KERR_TIMEOUT) return HF_ERR_TIMEOUT;
+    if (bits & HF_KERR_OVERFLOW) return HF_ERR_OVERFLOW;
+    if (bits & HF_KERR_CORRUPT) return HF_ERR_CORRUPT;
+    return HF_OK;
+}
+
+int use_device(hf_ctx* ctx) {
+    HF_HIP(hipSetDevice(ctx->device));
+    return HF_OK;
+}
+
+void tic(hf_ctx* ctx) {
+    if (ctx->timing) {
+        (void)hipEventRecord(ctx->ev0, ctx->stream);
+    }
+}
+void toc(hf_ctx* ctx) {
+    if (ctx->timing) {
+        (void)hipEventRecord(ctx->ev1, ctx->stream);
+        ctx->timed = 1;
+    }
+}
+
+// run one table stage: h_io (pinned) -> device -> kernel -> h_io, synchronous
+int run_stage(hf_ctx* ctx, int N, int op, int lmax, unsigned long long thr) {
+    ctx->h_io->status = -1;
+    HF_HIP(hipMemcpyAsync(ctx->d_io, ctx->h_io, sizeof(hf_stage_io), hipMemcpyHostToDevice,
+                          ctx->stream));
+    hf_launch_stage(ctx->d_io, N, op, lmax, thr, ctx->stream);
+    HF_HIP(hipGetLastError());
+    HF_HIP(hipMemcpyAsync(ctx->h_io, ctx->d_io, sizeof(hf_stage_io), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    HF_HIP(hipStreamSynchronize(ctx->stream));
+    return ctx->h_io->status == 0 ? HF_OK : HF_ERR_HIP;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hf_abi_version(void) { return HF_ABI_VERSION; }
+
+const char* hf_error_string(int code) {
+    switch (code) {
+        case HF_OK: return "ok";
+        case HF_ERR_ARG: return "bad argument";
+        case HF_ERR_ALIGN: return "device pointer not 16-byte aligned";
+        case HF_ERR_RANGE: return "value out of range";
+        case HF_ERR_HIP: return "HIP runtime error";
+        case HF_ERR_OVERFLOW: return "payload buffer too small";
+        case HF_ERR_TIMEOUT: return "in-kernel wait timed out";
+        case HF_ERR_CORRUPT: return "corrupt payload or offsets";
+        case HF_ERR_NOMEM: return "out of memory";
+        default: return "unknown error";
+    }
+}
+
+int hf_ctx_create(hf_ctx** out, int device, void* stream) {
+    if (!out) return HF_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return HF_ERR_HIP;
+    hf_ctx* ctx = new (std::nothrow) hf_ctx();
+    if (!ctx) return HF_ERR_NOMEM;
+    memset(ctx, 0, sizeof(*ctx));
+    ctx->device = device;
+    ctx->stream = reinterpret_cast<hipStream_t>(stream);
+    bool ok = hipSetDevice(device) == hipSuccess;
+    hipDeviceProp_t prop;
+    ok = ok && hipGetDeviceProperties(&prop, device) == hipSuccess;
+    ctx->num_cu = ok ? prop.multiProcessorCount : 0;
+    ok = ok && hipMalloc(&ctx->d_io, sizeof(hf_stage_io)) == hipSuccess;
+    ok = ok && hipHostMalloc(&ctx->h_io, sizeof(hf_stage_io)) == hipSuccess;
+    ok = ok && hipMalloc(&ctx->d_cb, HF_CODEBOOK_DEV_BYTES) == hipSuccess;
+    ok = ok && hipHostMalloc(&ctx->h_cb, HF_CODEBOOK_DEV_BYTES) == hipSuccess;
+    ok = ok && hipMalloc(&ctx->d_freq, 256 * sizeof(unsigned long long)) == hipSuccess;
+    ok = ok && hipHostMalloc(&ctx->h_freq, 256 * sizeof(unsigned long long)) == hipSuccess;
+    ok = ok && hipMalloc(&ctx->d_ctl, 64) == hipSuccess;
+    ok = ok && hipHostMalloc(&ctx->h_ctl, 64) == hipSuccess;
+    ok = ok && hipMalloc(&ctx->d_spill, hf_encode_spill_bytes(ctx->num_cu)) == hipSuccess;
+    ok = ok && hipEventCreate(&ctx->ev0) == hipSuccess;
+    ok = ok && hipEventCreate(&ctx->ev1) == hipSuccess;
+    if (!ok) {
+        hf_ctx_destroy(ctx);
+        return HF_ERR_HIP;
+    }
+    *out = ctx;
+    return HF_OK;
+}
+
+int hf_ctx_destroy(hf_ctx* ctx) {
+    if (!ctx) return HF_ERR_ARG;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream || ctx->d_io) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_io) (void)hipFree(ctx->d_io);
+    if (ctx->h_io) (void)hipHostFree(ctx->h_io);
+    if (ctx->d_cb) (void)hipFree(ctx->d_cb);
+    if (ctx->h_cb) (void)hipHostFree(ctx->h_cb);
+    if (ctx->d_freq) (void)hipFree(ctx->d_freq);
+    if (ctx->h_freq) (void)hipHostFree(ctx->h_freq);
+    if (ctx->d_desc) (void)hipFree(ctx->d_desc);
+    if (ctx->d_ctl) (void)hipFree(ctx->d_ctl);
+    if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
+    if (ctx->d_spill) (void)hipFree(ctx->d_spill);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+    return HF_OK;
+}
+
+int hf_sync(hf_ctx* ctx) {
+    if (!ctx) return HF_ERR_ARG;
+    if (int rc = use_device(ctx)) return rc;
+    HF_HIP(hipStreamSynchronize(ctx->stream));
+    return HF_OK;
+}
+
+int hf_flush(hf_ctx* ctx) {
+    if (!ctx) return HF_ERR_ARG;
+    if (int rc = use_device(ctx)) return rc;
+    HF_HIP(hipStreamSynchronize(ctx->stream));
+    HF_HIP(hipMemsetAsync(ctx->d_freq, 0, 256 * sizeof(unsigned long long), ctx->stream));
+    HF_HIP(hipMemsetAsync(ctx->d_ctl, 0, 64, ctx->stream));
+    HF_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->last_hip = 0;
+    ctx->timed = 0;
+    return HF_OK;
+}
+
+int hf_last_hip_error(hf_ctx* ctx) { return ctx ? ctx->last_hip : 0; }
+
+int hf_set_timing(hf_ctx* ctx, int enabled) {
+    if (!ctx) return HF_ERR_ARG;
+    ctx->timing = enabled != 0;
+    ctx->timed = 0;
+    return HF_OK;
+}
+
+int hf_last_kernel_ms(hf_ctx* ctx, float* ms) {
+    if (!ctx || !ms) return HF_ERR_ARG;
+    if (!ctx->timed) return HF_ERR_ARG;
+    if (int rc = use_device(ctx)) return rc;
+    HF_HIP(hipEventSynchronize(ctx->ev1));
+    HF_HIP(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return HF_OK;
+}
+
+/* ---- SymbolStat ---------------------------------------------------------------------------- */
+int hf_symbol_stat_dev(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
+                       uint64_t* d_freq256) {
+    if (!ctx || !d_freq256 || !layout_ok(layout) || (n && !d_data)) return HF_ERR_ARG;
+    if (!aligned16(d_data) || !aligned16(d_freq256)) return HF_ERR_ALIGN;
+    if (n > (1ull << 40)) return HF_ERR_RANGE;
+    if (int rc = use_device(ctx)) return rc;
+    tic(ctx);
+    hf_launch_hist(d_data, n, norm_layout(layout), reinterpret_cast<unsigned long long*>(d_freq256),
+                   ctx->num_cu, ctx->stream);
+    toc(ctx);
+    HF_HIP(hipGetLastError());
+    return HF_OK;
+}
+
+int hf_symbol_stat(hf_ctx* ctx, const void* d_data, uint64_t n, int layout, int N, int wt_width,
+                   uint64_t* h_freq) {
+    if (!ctx || !h_freq || !layout_ok(layout) || (n && !d_data)) return HF_ERR_ARG;
+    if (N < 2 || N > 256 || !is_pow2(N) || wt_width < 1 || wt_width > 64) return HF_ERR_ARG;
+    if (int rc = use_device(ctx)) return rc;
+    HF_HIP(hipMemsetAsync(ctx->d_freq, 0, 256 * sizeof(unsigned long long), ctx->stream));
+    if (int rc = hf_symbol_stat_dev(ctx, d_data, n, layout,
+                                    reinterpret_cast<uint64_t*>(ctx->d_freq)))
+        return rc;
+    HF_HIP(hipMemcpyAsync(ctx->h_freq, ctx->d_freq, 256 * sizeof(unsigned long long),
+                          hipMemcpyDeviceToHost, ctx->stream));
+    HF_HIP(hipStreamSynchronize(ctx->stream));
+    // the RTL indexes its N counters with the low log2(N) bits of the symbol
+    // (symbol_stat.scala:36-37) and its W-bit adds wrap
+    const uint64_t m = mask_w(wt_width);
+    for (int j = 0; j < N; ++j) h_freq[j] = 0;
+    for (int s = 0; s < 256; ++s) h_freq[s & (N - 1)] = (h_freq[s & (N - 1)] + ctx->h_freq[s]) & m;
+    return HF_OK;
+}
+
+/* ---- SymbolSort ---------------------------------------------------------------------------- */
+int hf_symbol_sort(hf_ctx* ctx, const uint64_t* h_freq, int N, uint64_t* h_sorted,
+                   uint16_t* h_rank2sym) {
+    if (!ctx || !h_freq || !h_sorted || N < 2 || N > 256) return HF_ERR_ARG;
+    for (int i = 0; i < N; ++i)
+        if (h_freq[i] >> 56) return HF_ERR_RANGE;
+    if (int rc = use_device(ctx)) return rc;
+    memcpy(ctx->h_io->freq, h_freq, sizeof(uint64_t) * (size_t)N);
+    if (int rc = run_stage(ctx, N, HF_OP_SORT, 0, 0)) return rc;
+    memcpy(h_sorted, ctx->h_io->sorted, sizeof(uint64_t) * (size_t)N);
+    if (h_rank2sym) memcpy(h_rank2sym, ctx->h_io->rank2sym, sizeof(uint16_t) * (size_t)N);
+    return HF_OK;
+}
+
+/* ---- ShannonEntropy + AdaptiveThreshold ------------------------------------------------------ */
+int hf_entropy(hf_ctx* ctx, const uint64_t* h_freq, int N, uint32_t* entropy_q16,
+               int* compression_mode) {
+    if (!ctx || !h_freq || !entropy_q16 || N < 2 || N > 256) return HF_ERR_ARG;
+    uint64_t tot = 0;
+    (void)tot;
+    for (int i = 0; i < N; ++i) {
+        if (h_freq[i] >> 56) return HF_ERR_RANGE;
+        tot += h_freq[i];
+    }
+    if (int rc = use_device(ctx)) return rc;
+    memcpy(ctx->h_io->freq, h_freq, sizeof(uint64_t) * (size_t)N);
+    if (int rc = run_stage(ctx, N, HF_OP_ENTROPY, 0, 0)) return rc;
+    *entropy_q16 = ctx->h_io->entropy_q16;
+    if (compression_mode) *compression_mode = (int)ctx->h_io->mode;
+    return HF_OK;
+}
+
+/* ---- HuffmanTreeBuilder ---------------------------------------------------------------------- */
+int hf_tree_build(hf_ctx* ctx, const uint64_t* h_freqs, int N, int wt_width, uint64_t* h_weights,
+                  uint16_t* h_lefts, uint16_t* h_rights, uint16_t* h_root, uint16_t* h_depths) {
+    if (!ctx || !h_freqs || N < 2 || N > 256) return HF_ERR_ARG;
+    if (wt_width != 32 && wt_width != 64) return HF_ERR_ARG;
+    // the merge order equals the RTL's only while no W-bit sum wraps and no valid weight
+    // reaches the all-ones mask value (tree_build.scala:48-52)
+    const uint64_t lim = wt_width == 32 ? 0xFFFFFFFFull : (1ull << 56);
+    uint64_t tot = 0;
+    for (int i = 0; i < N; ++i) {
+        if (h_freqs[i] >= lim) return HF_ERR_RANGE;
+        tot += h_freqs[i];
+        if (tot >= lim) return HF_ERR_RANGE;
+    }
+    if (int rc = use_device(ctx)) return rc;
+    memcpy(ctx->h_io->freq, h_freqs, sizeof(uint64_t) * (size_t)N);
+    if (int rc = run_stage(ctx, N, HF_OP_TREE, 0, 0)) return rc;
+    const int M = 2 * N - 1;
+    if (h_weights) memcpy(h_weights, ctx->h_io->weights, sizeof(uint64_t) * (size_t)M);
+    if (h_lefts) memcpy(h_lefts, ctx->h_io->lefts, sizeof(uint16_t) * (size_t)M);
+    if (h_rights) memcpy(h_rights, ctx->h_io->rights, sizeof(uint16_t) * (size_t)M);
+    if (h_root) *h_root = (uint16_t)ctx->h_io->root;
+    if (h_depths) memcpy(h_depths, ctx->h_io->depths, sizeof(uint16_t) * (size_t)N);
+    return HF_OK;
+}
+
+/* ---- tree_adjust ----------------------------------------------------------------------------- */
+int hf_tree_adjust(hf_ctx* ctx, const uint16_t* h_depths_in, int N, int max_depth,
+                   uint16_t* h_depths_out) {
+    if (!ctx || !h_depths_in || !h_depths_out || N < 2 || N > 256) return HF_ERR_ARG;
+    if (max_depth < 1 || max_depth > HF_MAX_CODE_LEN || (1 << max_depth) < N) return HF_ERR_ARG;
+    if (int rc = use_device(ctx)) return rc;
+    memcpy(ctx->h_io->depths, h_depths_in, sizeof(uint16_t) * (size_t)N);
+    if (int rc = run_stage(ctx, N, HF_OP_ADJUST, max_depth, 0)) return rc;
+    memcpy(h_depths_out, ctx->h_io->adj, sizeof(uint16_t) * (size_t)N);
+    return HF_OK;
+}
+
+/* ---- EntropyAwareTreeBuilder ------------------------------------------------------------------- */
+int hf_codebook(hf_ctx* ctx, const uint64_t* h_freq, int N, const hf_entropy_config* cfg,
+                uint16_t* h_code, uint8_t* h_len) {
+    if (!ctx || !h_freq || !h_code || !h_len || N < 2 || N > 256) return HF_ERR_ARG;
+    int lmax = HF_MAX_CODE_LEN;
+    unsigned long long thr = 0;
+    if (cfg) {
+        if (cfg->tree_depth_limit) lmax = (int)cfg->tree_depth_limit;
+        thr = cfg->min_freq_threshold;
+    }
+    if (lmax < 1 || lmax > HF_MAX_CODE_LEN || (1 << lmax) < N) return HF_ERR_ARG;
+    uint64_t tot = 0;
+    for (int i = 0; i < N; ++i) {
+        if (h_freq[i] >> 56) return HF_ERR_RANGE;
+        tot += h_freq[i];
+        if (tot >> 56) return HF_ERR_RANGE;
+    }
+    if (int rc = use_device(ctx)) return rc;
+    memcpy(ctx->h_io->freq, h_freq, sizeof(uint64_t) * (size_t)N);
+    if (int rc = run_stage(ctx, N, HF_OP_CODEBOOK, lmax, thr)) return rc;
+    memcpy(h_code, ctx->h_io->code, sizeof(uint16_t) * (size_t)N);
+    memcpy(h_len, ctx->h_io->len, (size_t)N);
+    return HF_OK;
+}
+
+/* ---- front half of EntropyAwareHuffmanSystem, on the device ------------------------------------ */
+int hf_system_codebook_dev(hf_ctx* ctx, const uint64_t* d_freq256, int mode,
+                           uint64_t min_freq_threshold, void* d_codebook) {
+    if (!ctx || !d_freq256 || !d_codebook) return HF_ERR_ARG;
+    if (mode != HF_MODE_BYPASS && mode != HF_MODE_HUFFMAN && mode != HF_MODE_AUTO) return HF_ERR_ARG;
+    if (!aligned16(d_freq256) || !aligned16(d_codebook)) return HF_ERR_ALIGN;
+    if (int rc = use_device(ctx)) return rc;
+    hf_cb_dev* cb = reinterpret_cast<hf_cb_dev*>(d_codebook);
+    tic(ctx);
+    hf_launch_system(reinterpret_cast<const unsigned long long*>(d_freq256), mode,
+                     min_freq_threshold, cb, ctx->stream);
+    hf_launch_tables(cb, ctx->stream);
+    toc(ctx);
+    HF_HIP(hipGetLastError());
+    return HF_OK;
+}
+
+/* ---- MemWrapper ---------------------------------------------------------------------------------- */
+int hf_codebook_upload(hf_ctx* ctx, const uint16_t* h_code, const uint8_t* h_len, int mode,
+                       void* d_codebook) {
+    if (!ctx || !h_code || !h_len || !d_codebook) return HF_ERR_ARG;
+    if (mode != HF_MODE_BYPASS && mode != HF_MODE_HUFFMAN) return HF_ERR_ARG;
+    if (!aligned16(d_codebook)) return HF_ERR_ALIGN;
+    for (int s = 0; s < 256; ++s)
+        if (h_len[s] > HF_MAX_CODE_LEN) return HF_ERR_RANGE;
+    if (int rc = use_device(ctx)) return rc;
+    hf_cb_dev* h = ctx->h_cb;
+    memset(h, 0, sizeof(hf_cb_dev));
+    for (int s = 0; s < 256; ++s) {
+        const uint32_t len = mode == HF_MODE_BYPASS ? 8u : h_len[s];
+        const uint32_t code = mode == HF_MODE_BYPASS ? (uint32_t)s : h_code[s];
+        h->enc[s] = (code & (len ? ((1u << len) - 1u) : 0u)) | (len << 16);
+        h->code[s] = (uint16_t)(h->enc[s] & 0xFFFFu);
+        h->len[s] = (uint8_t)len;
+    }
+    h->mode = (uint32_t)mode;
+    hf_cb_dev* cb = reinterpret_cast<hf_cb_dev*>(d_codebook);
+    HF_HIP(hipMemcpyAsync(cb, h, sizeof(hf_cb_dev), hipMemcpyHostToDevice, ctx->stream));
+    hf_launch_tables(cb, ctx->stream);
+    HF_HIP(hipGetLastError());
+    HF_HIP(hipStreamSynchronize(ctx->stream));
+    return HF_OK;
+}
+
+int hf_codebook_download(hf_ctx* ctx, const void* d_codebook, uint16_t* h_code, uint8_t* h_len,
+                         int* mode, uint32_t* entropy_q16) {
+    if (!ctx || !d_codebook) return HF_ERR_ARG;
+    if (int rc = use_device(ctx)) return rc;
+    HF_HIP(hipMemcpyAsync(ctx->h_cb, d_codebook, sizeof(hf_cb_dev), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    HF_HIP(hipStreamSynchronize(ctx->stream));
+    if (h_code) memcpy(h_code, ctx->h_cb->code, sizeof(uint16_t) * 256);
+    if (h_len) memcpy(h_len, ctx->h_cb->len, 256);
+    if (mode) *mode = (int)ctx->h_cb->mode;
+    if (entropy_q16) *entropy_q16 = ctx->h_cb->entropy_q16;
+    return HF_OK;
+}
+
+/* ---- encoder ------------------------------------------------------------------------------------- */
+int hf_encode_pairs(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
+                    const void* d_codebook, hf_code_beat* d_beats) {
+    if (!ctx || !d_codebook || !layout_ok(layout) || (n && (!d_data || !d_beats)))
+        return HF_ERR_ARG;
+    if (int rc = use_device(ctx)) return rc;
+    hf_launch_pairs(d_data, n, norm_layout(layout), reinterpret_cast<const hf_cb_dev*>(d_codebook),
+                    d_beats, ctx->stream);
+    HF_HIP(hipGetLastError());
+    return HF_OK;
+}
+
+uint64_t hf_num_chunks(uint64_t n) { return (n + HF_CHUNK_SYMS - 1) / HF_CHUNK_SYMS; }
+
+uint64_t hf_payload_bound_words(uint64_t n) { return hf_num_chunks(n) * 64ull * 129ull; }
+
+int hf_encode(hf_ctx* ctx, const void* d_data, uint64_t n, int layout, const void* d_codebook,
+              uint8_t* d_side, uint32_t* d_payload, uint64_t payload_cap_words,
+              uint32_t* d_chunk_off, uint64_t* h_total_words) {
+    if (!ctx || !d_codebook || !d_chunk_off || !layout_ok(layout)) return HF_ERR_ARG;
+    if (n && (!d_data || !d_payload)) return HF_ERR_ARG;
+    const int lay = norm_layout(layout);
+    if (lay == HF_LAYOUT_BF16_EXP && n && !d_side) return HF_ERR_ARG;
+    if (!aligned16(d_data) || !aligned16(d_side) || !aligned16(d_payload) ||
+        !aligned16(d_chunk_off) || !aligned16(d_codebook))
+        return HF_ERR_ALIGN;
+    if (n > (1ull << 40)) return HF_ERR_RANGE;
+    if (int rc = use_device(ctx)) return rc;
+    const uint64_t nchunks = hf_num_chunks(n);
+    if (nchunks > ctx->desc_cap) {
+        if (ctx->d_desc) {
+            HF_HIP(hipStreamSynchronize(ctx->stream));
+            HF_HIP(hipFree(ctx->d_desc));
+            ctx->d_desc = nullptr;
+            ctx->desc_cap = 0;
+        }
+        const size_t cap = (size_t)((nchunks + 1023) & ~1023ull);
+        HF_HIP(hipMalloc(&ctx->d_desc, cap * sizeof(unsigned long long)));
+        ctx->desc_cap = cap;
+    }
+    HF_HIP(hipMemsetAsync(ctx->d_ctl, 0, 64, ctx->stream));
+    if (nchunks == 0) {
+        HF_HIP(hipMemsetAsync(d_chunk_off, 0, sizeof(uint32_t), ctx->stream));
+    } else {
+        HF_HIP(hipMemsetAsync(ctx->d_desc, 0, ((nchunks + 1) & ~1ull) * sizeof(unsigned long long),
+                              ctx->stream));
+        tic(ctx);
+        hf_launch_encode(d_data, n, lay, reinterpret_cast<const hf_cb_dev*>(d_codebook), d_side,
+                         d_payload, payload_cap_words, d_chunk_off, ctx->d_desc, ctx->d_ctl,
+                         ctx->d_spill, ctx->d_ctl + 1, ctx->num_cu, ctx->stream);
+        toc(ctx);
+        HF_HIP(hipGetLastError());
+    }
+    if (h_total_words) {
+        HF_HIP(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl, 64, hipMemcpyDeviceToHost, ctx->stream));
+        HF_HIP(hipMemcpyAsync(ctx->h_ctl + 8, d_chunk_off + nchunks, sizeof(uint32_t),
+                              hipMemcpyDeviceToHost, ctx->stream));
+        HF_HIP(hipStreamSynchronize(ctx->stream));
+        *h_total_words = ctx->h_ctl[8];
+        return kerr_to_code(ctx->h_ctl[1]);
+    }
+    return HF_OK;
+}
+
+/* ---- decoder ------------------------------------------------------------------------------------- */
+int hf_decode(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
+              const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n, int layout,
+              const void* d_codebook, void* d_out, int check) {
+    if (!ctx || !d_codebook || !layout_ok(layout)) return HF_ERR_ARG;
+    if (n && (!d_payload || !d_chunk_off || !d_out)) return HF_ERR_ARG;
+    const int lay = norm_layout(layout);
+    if (lay == HF_LAYOUT_BF16_EXP && n && !d_side) return HF_ERR_ARG;
+    if (!aligned16(d_payload) || !aligned16(d_side) || !aligned16(d_out) ||
+        !aligned16(d_chunk_off) || !aligned16(d_codebook))
+        return HF_ERR_ALIGN;
+    if (n > (1ull << 40)) return HF_ERR_RANGE;
+    if (int rc = use_device(ctx)) return rc;
+    HF_HIP(hipMemsetAsync(ctx->d_ctl, 0, 64, ctx->stream));
+    if (n) {
+        tic(ctx);
+        hf_launch_decode(d_payload, payload_words, d_chunk_off, d_side, n, lay,
+                         reinterpret_cast<const hf_cb_dev*>(d_codebook), d_out, ctx->d_ctl + 1,
+                         ctx->num_cu, ctx->stream);
+        toc(ctx);
+        HF_HIP(hipGetLastError());
+    }
+    if (check) {
+        HF_HIP(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl, 64, hipMemcpyDeviceToHost, ctx->stream));
+        HF_HIP(hipStreamSynchronize(ctx->stream));
+        return kerr_to_code(ctx->h_ctl[1]);
+    }
+    return HF_OK;
+}
+
+/* ---- TreeQualityAnalyzer --------------------------------------------------------------------------
+ * Host arithmetic with the RTL's widths (tree_q_analyser.scala:21-47): total is a W-bit sum,
+ * each freq*len product and their sum keep W+6 bits, weighted_length is a 32-bit wire,
+ * avg_length_calc keeps (weighted << 8) / total, the three outputs are 16 bits wide. */
+int hf_quality(hf_ctx* ctx, const uint64_t* h_freq, const uint8_t* h_len, int N, int wt_width,
+               uint16_t* avg_len_q8, uint16_t* efficiency, uint16_t* compression_ratio) {
+    (void)ctx;
+    if (!h_freq || !h_len || N < 2 || N > 256 || wt_width < 1 || wt_width > 64) return HF_ERR_ARG;
+    const uint64_t m = mask_w(wt_width);
+    uint64_t total = 0;
+    unsigned __int128 acc = 0;
+    for (int i = 0; i < N; ++i) {
+        const uint64_t f = h_freq[i] & m;
+        total = (total + f) & m;
+        acc += (unsigned __int128)f * (uint64_t)(h_len[i] & 63u);
+    }
+    acc &= (((unsigned __int128)1) << (wt_width + 6)) - 1;
+    const uint64_t weighted = (uint64_t)acc & 0xFFFFFFFFull;
+    if (total == 0) return HF_ERR_RANGE;  // the RTL divides by zero here
+    const uint64_t avg = (weighted << 8) / total;
+    if (avg == 0) return HF_ERR_RANGE;
+    const uint64_t bits = (uint64_t)log2ceil_i(N);
+    const uint64_t theo = (bits << 8) & 0xFFFFull;
+    if (avg_len_q8) *avg_len_q8 = (uint16_t)avg;
+    if (efficiency) *efficiency = (uint16_t)((theo << 8) / avg);
+    if (compression_ratio) *compression_ratio = (uint16_t)((avg << 8) / (bits << 8));
+    return HF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,105 @@
+// Shared declarations of libhuffhip's translation units (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/huffhip.h"
+
+#define HF_LANES 64
+#define HF_GROUP 8          // consecutive symbols a lane takes per round
+#define HF_ROUNDS 32        // rounds per chunk
+#define HF_LANE_SYMS 256    // HF_GROUP * HF_ROUNDS
+#define HF_LUT_BITS 12      // first-level decode table width
+#define HF_LUT_SIZE (1 << HF_LUT_BITS)
+
+// Device-resident codebook (HF_CODEBOOK_DEV_BYTES reserves room for it).
+struct hf_cb_dev {
+    uint32_t enc[256];           // code | len << 16, by raw symbol
+    uint16_t lut[HF_LUT_SIZE];   // sym << 8 | len for codes of <= HF_LUT_BITS bits, 0 = escape
+    uint16_t code[256];
+    uint8_t len[256];
+    uint8_t long_syms[256];      // symbols whose code is longer than HF_LUT_BITS
+    uint32_t n_long;
+    uint32_t mode;               // HF_MODE_BYPASS / HF_MODE_HUFFMAN actually in force
+    uint32_t entropy_q16;
+    uint32_t entropy_mode;       // what the entropy decision alone says
+    uint32_t max_len;
+    uint32_t pad[3];
+};
+static_assert(sizeof(hf_cb_dev) <= HF_CODEBOOK_DEV_BYTES, "codebook struct outgrew its slot");
+
+// Global-memory I/O block of the single-wavefront table stages.
+struct hf_stage_io {
+    uint64_t freq[256];
+    uint64_t sorted[256];
+    uint64_t weights[511];
+    uint64_t pad0;
+    uint16_t rank2sym[256];
+    uint16_t lefts[512];
+    uint16_t rights[512];
+    uint16_t depths[256];
+    uint16_t adj[256];
+    uint16_t code[256];
+    uint8_t len[256];
+    uint32_t root;
+    uint32_t entropy_q16;
+    uint32_t mode;
+    int32_t status;
+    uint32_t migrate_steps;
+    uint32_t pad1[3];
+};
+
+enum hf_stage_op {
+    HF_OP_SORT = 1,
+    HF_OP_ENTROPY = 2,
+    HF_OP_TREE = 3,
+    HF_OP_ADJUST = 4,
+    HF_OP_CODEBOOK = 5,
+};
+
+// in-kernel error bits accumulated in the ctx error word
+#define HF_KERR_TIMEOUT 1u
+#define HF_KERR_OVERFLOW 2u
+#define HF_KERR_CORRUPT 4u
+
+// launchers (one per translation unit)
+void hf_launch_hist(const void* d_data, uint64_t n, int layout, unsigned long long* d_freq256,
+                    int num_cu, hipStream_t s);
+void hf_launch_stage(hf_stage_io* io, int N, int op, int lmax, unsigned long long thr,
+                     hipStream_t s);
+void hf_launch_system(const unsigned long long* d_freq256, int mode, unsigned long long thr,
+                      hf_cb_dev* cb, hipStream_t s);
+void hf_launch_tables(hf_cb_dev* cb, hipStream_t s);
+void hf_launch_pairs(const void* d_data, uint64_t n, int layout, const hf_cb_dev* cb,
+                     hf_code_beat* out, hipStream_t s);
+void hf_launch_encode(const void* d_data, uint64_t n, int layout, const hf_cb_dev* cb,
+                      uint8_t* d_side, uint32_t* d_payload, uint64_t cap_words,
+                      uint32_t* d_chunk_off, unsigned long long* d_desc, uint32_t* d_ticket,
+                      uint32_t* d_spill, uint32_t* d_err, int num_cu, hipStream_t s);
+size_t hf_encode_spill_bytes(int num_cu);
+void hf_launch_decode(const uint32_t* d_payload, uint64_t payload_words,
+                      const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n, int layout,
+                      const hf_cb_dev* cb, void* d_out, uint32_t* d_err, int num_cu,
+                      hipStream_t s);
+
+#ifdef __HIPCC__
+__device__ __forceinline__ int hf_lane() { return (int)__lane_id(); }
+
+// wave-wide sum of a 32-bit value (all 64 lanes must call)
+__device__ __forceinline__ uint32_t hf_wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ unsigned long long hf_wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// number of set bits of `m` below this lane
+__device__ __forceinline__ uint32_t hf_mbcnt(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                     __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+#endif

@@ -1,0 +1,190 @@
+/*
+ * huffhip.h -- C ABI of libhuffhip.so, the MI355X (gfx950) Huffman codec.
+ *
+ * The reference (liuyuxivapor/huffman) is Chisel RTL and has no software FFI; its interface
+ * contract is the IO bundle of each hardware module.  Every entry point below replaces one of
+ * those module boundaries and cites it.  Conventions shared by all calls:
+ *
+ *   - one opaque hf_ctx per (device, stream); a ctx is not thread safe, distinct ctxs are;
+ *   - every call returns 0 or a negative HF_ERR_* code and never throws; the RTL itself has no
+ *     error outputs (counters wrap silently), so anything it would silently mangle is an error;
+ *   - the caller owns all buffers.  Bulk data (symbols, payload, side bytes, chunk offsets)
+ *     are DEVICE pointers, 16-byte aligned; tables of at most a few KiB are HOST pointers
+ *     unless the name ends in _dev;
+ *   - calls taking host tables synchronise the ctx stream before returning; calls whose
+ *     outputs are all device-side only enqueue work (ordering = stream order);
+ *   - N ("depth"/"numLeaves" in the reference) is the alphabet size, 2 <= N <= 256.
+ */
+#ifndef HUFFHIP_H
+#define HUFFHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HF_ABI_VERSION 1
+
+/* error codes */
+#define HF_OK 0
+#define HF_ERR_ARG (-1)      /* null pointer, bad size, bad enum                          */
+#define HF_ERR_ALIGN (-2)    /* device pointer not 16-byte aligned                         */
+#define HF_ERR_RANGE (-3)    /* value outside what the arithmetic is defined for           */
+#define HF_ERR_HIP (-4)      /* a HIP runtime call failed (see hf_last_hip_error)          */
+#define HF_ERR_OVERFLOW (-5) /* payload buffer too small                                   */
+#define HF_ERR_TIMEOUT (-6)  /* an in-kernel bounded wait ran out                          */
+#define HF_ERR_CORRUPT (-7)  /* payload / offsets inconsistent                             */
+#define HF_ERR_NOMEM (-8)
+
+/* element layouts accepted by the front ends */
+#define HF_LAYOUT_U8 0       /* symbol = byte                                              */
+#define HF_LAYOUT_BF16_EXP 1 /* symbol = bf16 exponent (w>>7)&0xFF, side byte = sign|mantissa */
+#define HF_LAYOUT_FP8 2      /* fp8 E4M3/E5M2 byte taken whole, same as U8                  */
+
+/* packed-stream geometry */
+#define HF_CHUNK_SYMS 16384u /* symbols per chunk (one wavefront: 64 lanes x 256 symbols)  */
+#define HF_MAX_CODE_LEN 16
+
+/* compression_mode values (top_encoder.scala:20, adaptive_threshold.scala:18) */
+#define HF_MODE_BYPASS 0
+#define HF_MODE_HUFFMAN 1
+#define HF_MODE_AUTO 2 /* let the entropy decision choose (system calls only) */
+
+typedef struct hf_ctx hf_ctx;
+
+/* Device-resident codebook: encoder table, decoder lookup tables, mode.  Opaque; size and
+ * alignment are fixed so callers can place it in their own device allocations. */
+#define HF_CODEBOOK_DEV_BYTES 12288u
+
+/* entropy_config bundle of EntropyAwareTreeBuilder (entropy_aware_tree_builder.scala:9-13).
+ * As in the RTL only min_freq_threshold is honoured by the tree stage; tree_depth_limit = 0
+ * selects the RTL's hard-wired 16 (entropy_aware_tree_builder.scala:23). */
+typedef struct hf_entropy_config {
+    uint32_t encoding_mode;
+    uint32_t tree_depth_limit;
+    uint64_t min_freq_threshold;
+} hf_entropy_config;
+
+/* one beat of EntropyAwareHuffmanSystem.io.encoded_out (top_encoder.scala:17-21) */
+typedef struct hf_code_beat {
+    uint16_t code;
+    uint8_t length;
+    uint8_t compression_mode;
+} hf_code_beat;
+
+/* ---- context ----------------------------------------------------------------------------- */
+int hf_abi_version(void);
+/* `stream` is a hipStream_t (NULL = the device's default stream). */
+int hf_ctx_create(hf_ctx** out, int device, void* stream);
+int hf_ctx_destroy(hf_ctx* ctx);
+/* `flush` input of every module (symbol_stat.scala:51-57, symbol_sort.scala:107-110,
+ * entropy_aware_tree_builder.scala:166-168, top_encoder.scala:178-183): drop any in-flight
+ * block state; here: wait for the stream and clear the ctx's accumulators and error word. */
+int hf_flush(hf_ctx* ctx);
+int hf_sync(hf_ctx* ctx);
+const char* hf_error_string(int code);
+int hf_last_hip_error(hf_ctx* ctx);
+
+/* ---- SymbolStat (symbol_stat.scala:6-58) -------------------------------------------------- */
+/* start + stream of n beats + done: histogram of one block.  freq[s mod N] counts; the
+ * internal counters are 64 bit, the returned values are reduced mod 2^wt_width
+ * (wt_width in 1..64) as the RTL's W-bit registers would hold them.  N must be a power of 2. */
+int hf_symbol_stat(hf_ctx* ctx, const void* d_data, uint64_t n, int layout, int N, int wt_width,
+                   uint64_t* h_freq);
+/* Same block, counts left on the device: d_freq256 (uint64[256], by raw symbol) is
+ * ACCUMULATED into (zero it for a fresh block); no synchronisation. */
+int hf_symbol_stat_dev(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
+                       uint64_t* d_freq256);
+
+/* ---- SymbolSort (symbol_sort.scala:82-148) ------------------------------------------------ */
+/* sorted = counts in descending order (stable).  rank2sym (optional) carries the symbol
+ * identities the RTL drops: rank2sym[p] = index of the p-th largest count,
+ * total order (count desc, index asc). */
+int hf_symbol_sort(hf_ctx* ctx, const uint64_t* h_freq, int N, uint64_t* h_sorted,
+                   uint16_t* h_rank2sym);
+
+/* ---- ShannonEntropy + AdaptiveThreshold (shannon_entropy.scala:11-118,
+ *      adaptive_threshold.scala:11-87) ------------------------------------------------------- */
+/* entropy_out (Q16.16) with the RTL's arithmetic at W = 32 and the loop run N times;
+ * compression_mode = 1 (Huffman) / 0 (bypass).  Totals above 32 bits are scaled down by a
+ * right shift of every count first. */
+int hf_entropy(hf_ctx* ctx, const uint64_t* h_freq, int N, uint32_t* entropy_q16,
+               int* compression_mode);
+
+/* ---- HuffmanTreeBuilder (tree_build.scala:17-140) ----------------------------------------- */
+/* freqs[N] in the caller's index order (the system passes them sorted descending).
+ * weights/lefts/rights have 2N-1 entries, entries below N as the RTL initialises them
+ * (weight = freq, children 0).  Merge priority (weight, index) as findTwoMin
+ * (tree_build.scala:47-72).  depths[N] are true leaf depths (the RTL's `depths` port is dead).
+ * wt_width: 32 or 64.  The sum of all freqs must stay below 2^wt_width - 1 (the RTL wraps;
+ * this call returns HF_ERR_RANGE instead). */
+int hf_tree_build(hf_ctx* ctx, const uint64_t* h_freqs, int N, int wt_width, uint64_t* h_weights,
+                  uint16_t* h_lefts, uint16_t* h_rights, uint16_t* h_root, uint16_t* h_depths);
+
+/* ---- tree_adjust (tree_adjust.scala:6-127) ------------------------------------------------- */
+/* Length limiter: BuildHist / Migrate / FillHoles / Assign-by-index with Kraft-correct moves.
+ * max_depth in 1..16 and 2^max_depth >= N. */
+int hf_tree_adjust(hf_ctx* ctx, const uint16_t* h_depths_in, int N, int max_depth,
+                   uint16_t* h_depths_out);
+
+/* ---- EntropyAwareTreeBuilder (entropy_aware_tree_builder.scala:6-169) ---------------------- */
+/* freq_in[N] -> code_out[N], length_out[N]; indices are the caller's (filter, tree, adjust,
+ * canonical codes in index order). */
+int hf_codebook(hf_ctx* ctx, const uint64_t* h_freq, int N, const hf_entropy_config* cfg,
+                uint16_t* h_code, uint8_t* h_len);
+
+/* ---- the front half of EntropyAwareHuffmanSystem (top_encoder.scala:29-139) ---------------- */
+/* Device pipeline over a 256-bin histogram by raw symbol: sort -> entropy decision ->
+ * codebook over ranks -> rank->symbol scatter -> device codebook with decode tables.
+ * mode: HF_MODE_BYPASS / HF_MODE_HUFFMAN force the choice, HF_MODE_AUTO follows the entropy
+ * decision.  No synchronisation. */
+int hf_system_codebook_dev(hf_ctx* ctx, const uint64_t* d_freq256, int mode,
+                           uint64_t min_freq_threshold, void* d_codebook);
+
+/* ---- MemWrapper (mem_wrapper.scala:6-87): the codebook store ------------------------------- */
+/* write port, all entries: build a device codebook from host tables indexed by symbol. */
+int hf_codebook_upload(hf_ctx* ctx, const uint16_t* h_code, const uint8_t* h_len, int mode,
+                       void* d_codebook);
+/* bulk read port: code_table / length_table / mode / entropy of a device codebook. */
+int hf_codebook_download(hf_ctx* ctx, const void* d_codebook, uint16_t* h_code, uint8_t* h_len,
+                         int* mode, uint32_t* entropy_q16);
+
+/* ---- encoder (top_encoder.scala:124-162) --------------------------------------------------- */
+/* One {code, length, compression_mode} beat per symbol, unpacked, as the RTL emits them. */
+int hf_encode_pairs(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
+                    const void* d_codebook, hf_code_beat* d_beats);
+
+/* Packed stream.  d_side (BF16_EXP only) receives n raw side bytes.  d_payload receives the
+ * payload words, d_chunk_off[c] the first word of chunk c and d_chunk_off[nchunks] the total
+ * (nchunks = ceil(n / HF_CHUNK_SYMS)).  payload_cap_words bounds what may be written.
+ * h_total_words == NULL: enqueue only.  Otherwise synchronise, return the total and report
+ * in-kernel errors. */
+int hf_encode(hf_ctx* ctx, const void* d_data, uint64_t n, int layout, const void* d_codebook,
+              uint8_t* d_side, uint32_t* d_payload, uint64_t payload_cap_words,
+              uint32_t* d_chunk_off, uint64_t* h_total_words);
+uint64_t hf_num_chunks(uint64_t n);
+/* worst case over all codebooks with lengths <= 16 */
+uint64_t hf_payload_bound_words(uint64_t n);
+
+/* ---- ParrallelHuffmanDecoder (decoder/top_decoder.scala:6-10, constructor only) ------------ */
+/* Rebuilds n elements of `layout` into d_out.  payload_words = size of the d_payload buffer
+ * (offsets pointing past it are reported, never followed).  `check` != 0: synchronise and
+ * report in-kernel errors. */
+int hf_decode(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
+              const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n, int layout,
+              const void* d_codebook, void* d_out, int check);
+
+/* ---- TreeQualityAnalyzer (tree_q_analyser.scala:10-47) ------------------------------------- */
+int hf_quality(hf_ctx* ctx, const uint64_t* h_freq, const uint8_t* h_len, int N, int wt_width,
+               uint16_t* avg_len_q8, uint16_t* efficiency, uint16_t* compression_ratio);
+
+/* ---- per-kernel device timing of the last call (milliseconds, for the bench) --------------- */
+int hf_last_kernel_ms(hf_ctx* ctx, float* ms);
+int hf_set_timing(hf_ctx* ctx, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HUFFHIP_H */

@@ -1,0 +1,562 @@
+/*
+ * hf_oracle.c -- CPU restatement of the liuyuxivapor/huffman encoder pipeline (plain C11).
+ *
+ * TEST INFRASTRUCTURE ONLY: see hf_oracle.h.  Every function cites the reference lines it
+ * follows.  The reference cannot be built here (Scala 2.13 + Chisel 6 need a JVM, sbt and
+ * firtool; none is installed), so this restatement is pinned by the known-answer vectors in
+ * the reference's own chiseltest specs (SymbolStat, SymbolSort) and, for everything the
+ * reference leaves broken or absent, is "parity unpinned".
+ */
+#include "hf_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+static inline uint64_t mask_w(int W) { return W >= 64 ? ~0ull : ((1ull << W) - 1ull); }
+
+static inline int log2ceil_i(int x) {
+    int b = 0;
+    while ((1 << b) < x) ++b;
+    return b;
+}
+
+/* ======================================================================================= */
+/* front end                                                                                */
+/* ======================================================================================= */
+
+void orc_symbolize(const void* data, size_t n, int layout, uint8_t* sym, uint8_t* side) {
+    if (layout == ORC_LAYOUT_BF16_EXP) {
+        const uint16_t* w = (const uint16_t*)data;
+        for (size_t i = 0; i < n; ++i) {
+            sym[i] = (uint8_t)((w[i] >> 7) & 0xFF);
+            if (side) side[i] = (uint8_t)(((w[i] >> 8) & 0x80) | (w[i] & 0x7F));
+        }
+    } else {
+        memcpy(sym, data, n);
+    }
+}
+
+void orc_desymbolize(const uint8_t* sym, const uint8_t* side, size_t n, int layout, void* out) {
+    if (layout == ORC_LAYOUT_BF16_EXP) {
+        uint16_t* w = (uint16_t*)out;
+        for (size_t i = 0; i < n; ++i)
+            w[i] = (uint16_t)(((uint16_t)(side[i] & 0x80) << 8) | ((uint16_t)sym[i] << 7) |
+                              (side[i] & 0x7F));
+    } else {
+        memcpy(out, sym, n);
+    }
+}
+
+/* ======================================================================================= */
+/* as written                                                                               */
+/* ======================================================================================= */
+
+/* symbol_stat.scala:34-38 -- `freq(sym) := freq(sym) + 1.U`; the Vec index keeps the low
+ * log2(N) bits of the symbol, the W-bit add wraps. */
+void orc_aw_symbol_stat(const uint8_t* sym, size_t n, int N, int W, uint64_t* freq) {
+    const uint64_t m = mask_w(W);
+    for (int i = 0; i < N; ++i) freq[i] = 0; /* symbol_stat.scala:27-31 clear on start */
+    for (size_t i = 0; i < n; ++i) {
+        int s = sym[i] & (N - 1);
+        freq[s] = (freq[s] + 1) & m;
+    }
+}
+
+/* symbol_sort.scala:125-142.  iterCnt runs 0 .. 2N-1; phase = ~iterCnt(0), i.e. 1 on even
+ * iterations: pairs (i, i+1) with i odd go first.  Swap only when a < b. */
+void orc_aw_symbol_sort(const uint64_t* in, int N, uint64_t* sorted, uint16_t* ids) {
+    uint64_t* v = sorted;
+    uint16_t* id = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)N);
+    uint64_t* nv = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)N);
+    uint16_t* nid = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)N);
+    for (int i = 0; i < N; ++i) {
+        v[i] = in[i];
+        id[i] = (uint16_t)i;
+    }
+    for (int iter = 0; iter < 2 * N; ++iter) {
+        int phase = (~iter) & 1;
+        /* all comparators of one pass read the old register values (registered update) */
+        memcpy(nv, v, sizeof(uint64_t) * (size_t)N);
+        memcpy(nid, id, sizeof(uint16_t) * (size_t)N);
+        for (int i = 0; i < N - 1; ++i) {
+            if ((i % 2) == phase && v[i] < v[i + 1]) {
+                nv[i] = v[i + 1];
+                nv[i + 1] = v[i];
+                nid[i] = id[i + 1];
+                nid[i + 1] = id[i];
+            }
+        }
+        memcpy(v, nv, sizeof(uint64_t) * (size_t)N);
+        memcpy(id, nid, sizeof(uint16_t) * (size_t)N);
+    }
+    if (ids) memcpy(ids, id, sizeof(uint16_t) * (size_t)N);
+    free(id);
+    free(nv);
+    free(nid);
+}
+
+/* tree_build.scala:47-72 (findTwoMin) and :90-131 (sInit, sMerge).
+ * Invalid nodes are masked to maxVal = 2^W - 1; the minimum is taken over all 2N-1 masked
+ * weights; the index is the PriorityEncoder (lowest index) over `masked == min && valid`,
+ * which yields the last index 2N-2 when nothing matches.  The second search masks the first
+ * index as well; the first node is still `valid` there, so it can match again when the second
+ * minimum equals maxVal. */
+void orc_aw_tree_build(const uint64_t* freqs, int N, int W, uint64_t* weights, uint16_t* lefts,
+                       uint16_t* rights, uint16_t* root, uint16_t* heights) {
+    const int M = 2 * N - 1;
+    const uint64_t m = mask_w(W);
+    const uint64_t maxVal = m; /* (1 << W) - 1 */
+    const unsigned depth_mask = (1u << log2ceil_i(N + 1)) - 1u; /* depthWidth, :20 */
+    uint8_t* valid = (uint8_t*)calloc((size_t)M, 1);
+    uint16_t* h = (uint16_t*)calloc((size_t)M, sizeof(uint16_t));
+    for (int i = 0; i < M; ++i) { /* sInit, :90-109 */
+        weights[i] = i < N ? (freqs[i] & m) : 0;
+        lefts[i] = 0;
+        rights[i] = 0;
+        valid[i] = i < N;
+    }
+    for (int k = N; k < M; ++k) { /* sMerge, :111-125 */
+        uint64_t min1 = maxVal;
+        for (int i = 0; i < M; ++i) {
+            uint64_t w = valid[i] ? weights[i] : maxVal;
+            if (w < min1) min1 = w;
+        }
+        int i1 = M - 1;
+        for (int i = 0; i < M; ++i)
+            if (valid[i] && weights[i] == min1) {
+                i1 = i;
+                break;
+            }
+        uint64_t min2 = maxVal;
+        for (int i = 0; i < M; ++i) {
+            uint64_t w = (i == i1 || !valid[i]) ? maxVal : weights[i];
+            if (w < min2) min2 = w;
+        }
+        int i2 = M - 1;
+        for (int i = 0; i < M; ++i) {
+            uint64_t w = (i == i1 || !valid[i]) ? maxVal : weights[i];
+            if (w == min2 && valid[i]) {
+                i2 = i;
+                break;
+            }
+        }
+        uint64_t wsum = (weights[i1] + weights[i2]) & m; /* :115, W-bit add */
+        uint16_t hh = (uint16_t)(((h[i1] >= h[i2] ? h[i1] : h[i2]) + 1u) & depth_mask); /* :120 */
+        weights[k] = wsum;
+        lefts[k] = (uint16_t)i1;
+        rights[k] = (uint16_t)i2;
+        h[k] = hh;
+        valid[i1] = 0;
+        valid[i2] = 0;
+        valid[k] = 1; /* last connect wins, :122-124 */
+    }
+    *root = (uint16_t)(M - 1); /* nodeCnt - 1, :128 */
+    if (heights) memcpy(heights, h, sizeof(uint16_t) * (size_t)M);
+    free(valid);
+    free(h);
+}
+
+/* entropy_aware_tree_builder.scala:118-127 */
+void orc_aw_code_start(const uint16_t* len, int N, uint16_t count[17], uint16_t code_start[17]) {
+    for (int d = 0; d < 17; ++d) {
+        unsigned c = 0;
+        for (int i = 0; i < N; ++i) c += (len[i] == d);
+        count[d] = (uint16_t)c;
+    }
+    code_start[0] = 0;
+    for (int d = 1; d < 17; ++d)
+        code_start[d] = (uint16_t)(((unsigned)code_start[d - 1] + count[d - 1]) << 1);
+}
+
+/* entropy_aware_tree_builder.scala:133-155: prefixSum(d+1) = prefixSum(d) + count(d),
+ * codes(i) = codeStart(len_i) + prefixSum(len_i), indices above 17 read as zero. */
+void orc_aw_codes_as_written(const uint16_t* len, int N, uint16_t* code) {
+    uint16_t count[17], cs[17], prefix[18];
+    orc_aw_code_start(len, N, count, cs);
+    prefix[0] = 0;
+    for (int d = 0; d <= 16; ++d) prefix[d + 1] = (uint16_t)(prefix[d] + count[d]);
+    for (int i = 0; i < N; ++i) {
+        unsigned l = len[i] & 31u; /* lvl.pad(5) */
+        uint16_t c = l < 17 ? cs[l] : 0;
+        uint16_t p = l < 18 ? prefix[l] : 0;
+        code[i] = (uint16_t)(c + p);
+    }
+}
+
+/* shannon_entropy.scala:58-109 with the loop body executed for every index 0..N-1.
+ * Chisel widths: prob is W+16 bits; k has log2Ceil(W) bits; the shift amount
+ * k + 1 + 16 - 8 is evaluated in max(log2Ceil(W), 5) bits; `1.U << amount` is 32 bits wide
+ * for W <= 32; x*k >> 16 and 2x are added in W+17 bits, the subtraction keeps W+17 bits;
+ * entropy_acc is a 32-bit register, so only bits 16..47 of prob * approx reach it. */
+uint32_t orc_aw_entropy_q16(const uint64_t* freq, int N, int W) {
+    const uint64_t m = mask_w(W);
+    const int kw = log2ceil_i(W);
+    const int sw = kw > 5 ? kw : 5;
+    uint64_t total = 0;
+    for (int i = 0; i < N; ++i) total = (total + (freq[i] & m)) & m; /* :62 */
+    uint32_t acc = 0;
+    for (int i = 0; i < N; ++i) {
+        uint64_t f = freq[i] & m;
+        if (f == 0 || total == 0) continue; /* :70 */
+        uint64_t prob = (f << 16) / total;  /* :72 */
+        unsigned k = (unsigned)(W - 1);     /* PriorityEncoder default = last index */
+        for (int b = W - 1; b >= 0; --b)
+            if ((prob >> b) & 1ull) {
+                k = (unsigned)(W - 1 - b);
+                break;
+            }
+        unsigned amt = (k + 1u) & ((1u << kw) - 1u); /* :78 */
+        amt = (amt + 16u) & ((1u << sw) - 1u);
+        amt = (amt - 8u) & ((1u << sw) - 1u);
+        uint64_t pow2 = 1ull << amt;
+        uint64_t xk = (prob * (uint64_t)k) >> 16; /* :81 */
+        uint64_t two_x = prob << 1;               /* :84 */
+        uint64_t approx = (xk + two_x - pow2) & ((1ull << (W + 17)) - 1ull); /* :87 */
+        uint64_t prod = prob * approx;            /* low 64 bits are exact */
+        acc += (uint32_t)(prod >> 16);            /* :90-91 */
+    }
+    return (uint32_t)(0x10000u - acc); /* :101 */
+}
+
+/* adaptive_threshold.scala:26-27 thresholds 0.5 and 6.0 in Q16; :65-79 decision. */
+int orc_aw_adaptive_mode(uint32_t e) {
+    if (e < 0x8000u) return 1;
+    if (e > 0x60000u) return 0;
+    return 1;
+}
+
+/* entropy_aware_tree_builder.scala:61-66 */
+void orc_aw_filter(const uint64_t* freq, int N, uint64_t thr, uint64_t* out) {
+    for (int i = 0; i < N; ++i) out[i] = freq[i] >= thr ? freq[i] : 0;
+}
+
+/* top_encoder.scala:131-137 (bypass table) and :148-162 (lookup mux) */
+void orc_aw_encode_pairs(const uint8_t* sym, size_t n, const uint16_t* code, const uint8_t* len,
+                         int mode, int sym_width, uint8_t* out4) {
+    for (size_t i = 0; i < n; ++i) {
+        uint16_t c;
+        uint8_t l;
+        if (mode == 0) {
+            c = sym[i];
+            l = (uint8_t)sym_width;
+        } else {
+            c = code[sym[i]];
+            l = len[sym[i]];
+        }
+        out4[4 * i + 0] = (uint8_t)(c & 0xFF);
+        out4[4 * i + 1] = (uint8_t)(c >> 8);
+        out4[4 * i + 2] = l;
+        out4[4 * i + 3] = (uint8_t)(mode & 1);
+    }
+}
+
+/* tree_q_analyser.scala:21-47.  total is a W-bit sum; each product is W+6 bits and the sum
+ * keeps W+6 bits; weighted_length is a 32-bit wire; avg_length_calc keeps 40 bits, the
+ * outputs are 16 bits. */
+int orc_aw_quality(const uint64_t* freq, const uint8_t* len, int N, int W, uint16_t* avg_len_q8,
+                   uint16_t* efficiency, uint16_t* compression_ratio) {
+    const uint64_t m = mask_w(W);
+    uint64_t total = 0;
+    unsigned __int128 acc = 0;
+    for (int i = 0; i < N; ++i) {
+        total = (total + (freq[i] & m)) & m;
+        acc += (unsigned __int128)(freq[i] & m) * (uint64_t)(len[i] & 63);
+    }
+    if (W + 6 < 128) acc &= (((unsigned __int128)1) << (W + 6)) - 1;
+    uint64_t weighted = (uint64_t)acc & 0xFFFFFFFFull; /* :22, :30 */
+    if (total == 0) return -1;
+    uint64_t avg = (weighted << 8) / total; /* :33 */
+    uint64_t theo = ((uint64_t)log2ceil_i(N) << 8) & 0xFFFF; /* :38 */
+    if (avg == 0) return -1;
+    uint64_t eff = (theo << 8) / avg; /* :41 */
+    uint64_t ub = (uint64_t)log2ceil_i(N);
+    if (ub == 0) return -1;
+    uint64_t ratio = (avg << 8) / (ub << 8); /* :46 */
+    *avg_len_q8 = (uint16_t)avg;
+    *efficiency = (uint16_t)eff;
+    *compression_ratio = (uint16_t)ratio;
+    return 0;
+}
+
+/* ======================================================================================= */
+/* repaired                                                                                 */
+/* ======================================================================================= */
+
+/* tree_build.scala:81 returns depthArr.take(numLeaves), which sInit zeroes (:97) and sMerge
+ * never writes (:120 writes index nodeCnt >= N only).  The intended output is the depth of
+ * each leaf below the root: walk lefts/rights from the root.  Children always have a lower
+ * index than their parent, so one descending sweep suffices. */
+void orc_rp_leaf_depths(const uint16_t* lefts, const uint16_t* rights, int root, int N,
+                        uint16_t* depths) {
+    const int M = 2 * N - 1;
+    uint16_t* d = (uint16_t*)calloc((size_t)M, sizeof(uint16_t));
+    for (int k = root; k >= N; --k) {
+        d[lefts[k]] = (uint16_t)(d[k] + 1);
+        d[rights[k]] = (uint16_t)(d[k] + 1);
+    }
+    memcpy(depths, d, sizeof(uint16_t) * (size_t)N);
+    free(d);
+}
+
+/* tree_adjust.scala keeps a depth histogram (sBuildHist :44-57), moves leaves between levels
+ * (sMigrate :59-82, sFillHoles :85-106) and deals the resulting depth multiset to indices in
+ * ascending order (sAssign :108-119).  As written the histogram is a last-connect, not a sum
+ * (:45-49), K comes from the previous run (:50-54), holesLeft is truncated to 6 bits
+ * (:34, :79), the level moves do not preserve the Kraft sum (:71-73, :96-98) and sAssign never
+ * terminates for power-of-two N (:24-25, :109).  This keeps the four phases and the
+ * assign-by-index rule with arithmetic that provably yields a prefix-code length set:
+ *   BuildHist  true histogram, depths above lmax clamped to lmax, kraft = sum hist[d] 2^(lmax-d)
+ *   Migrate    while kraft > 2^lmax: deepest level d < lmax with a leaf: move one leaf d -> d+1
+ *   FillHoles  holes = 2^lmax - kraft (cf. emptyL, :34): for d = lmax .. 2: while a leaf sits
+ *              at d and holes >= 2^(lmax-d): move it d -> d-1
+ *   Assign     index p = 0 .. N-1 takes the smallest remaining depth (:108-116)            */
+int orc_rp_tree_adjust(const uint16_t* depths_in, int N, int lmax, uint16_t* depths_out) {
+    if (lmax < 1 || lmax > 16 || (1l << lmax) < N) return -1;
+    uint32_t hist[17];
+    memset(hist, 0, sizeof hist);
+    for (int i = 0; i < N; ++i) {
+        int d = depths_in[i] > lmax ? lmax : depths_in[i];
+        hist[d]++;
+    }
+    uint64_t kraft = 0;
+    for (int d = 0; d <= lmax; ++d) kraft += (uint64_t)hist[d] << (lmax - d);
+    const uint64_t full = 1ull << lmax;
+    int steps = 0;
+    while (kraft > full) {
+        int d = lmax - 1;
+        while (d >= 0 && hist[d] == 0) --d;
+        if (d < 0) return -1; /* unreachable: all leaves at lmax means kraft = N <= 2^lmax */
+        hist[d]--;
+        hist[d + 1]++;
+        kraft -= 1ull << (lmax - d - 1);
+        ++steps;
+    }
+    uint64_t holes = full - kraft;
+    for (int d = lmax; d >= 2; --d) {
+        const uint64_t unit = 1ull << (lmax - d);
+        while (hist[d] > 0 && holes >= unit) {
+            hist[d]--;
+            hist[d - 1]++;
+            holes -= unit;
+        }
+    }
+    int d = 0;
+    for (int p = 0; p < N; ++p) {
+        while (d <= lmax && hist[d] == 0) ++d;
+        depths_out[p] = (uint16_t)d;
+        hist[d]--;
+    }
+    return steps;
+}
+
+/* The per-symbol offset as written (entropy_aware_tree_builder.scala:148-155) gives every
+ * symbol of one length the same code.  The commented-out original (:105-111) walks i upward
+ * handing out nextCode(len_i)++: the standard canonical assignment in index order.  count[0]
+ * is forced to zero so a zero length cannot shift the code space. */
+void orc_rp_canonical_codes(const uint16_t* len, int N, uint16_t* code) {
+    uint16_t count[17], cs[17];
+    for (int d = 0; d < 17; ++d) count[d] = 0;
+    for (int i = 0; i < N; ++i)
+        if (len[i] >= 1 && len[i] <= 16) count[len[i]]++;
+    cs[0] = 0;
+    for (int d = 1; d < 17; ++d) cs[d] = (uint16_t)(((unsigned)cs[d - 1] + count[d - 1]) << 1);
+    uint16_t next[17];
+    memcpy(next, cs, sizeof next);
+    for (int i = 0; i < N; ++i) {
+        if (len[i] >= 1 && len[i] <= 16)
+            code[i] = next[len[i]]++;
+        else
+            code[i] = 0;
+    }
+}
+
+/* EntropyAwareTreeBuilder FSM order (entropy_aware_tree_builder.scala:40): sFilter -> sBuild ->
+ * sAdjust -> sGenPrep/sGenExec, with the repaired pieces substituted. */
+int orc_rp_codebook(const uint64_t* freq, int N, int W, uint64_t thr, int lmax, uint16_t* code,
+                    uint8_t* len) {
+    const int M = 2 * N - 1;
+    uint64_t* filt = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)N);
+    uint64_t* wts = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)M);
+    uint16_t* l = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)M);
+    uint16_t* r = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)M);
+    uint16_t* dep = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)N);
+    uint16_t* adj = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)N);
+    uint16_t root;
+    orc_aw_filter(freq, N, thr, filt);
+    orc_aw_tree_build(filt, N, W, wts, l, r, &root, NULL);
+    orc_rp_leaf_depths(l, r, root, N, dep);
+    int rc = orc_rp_tree_adjust(dep, N, lmax, adj);
+    if (rc >= 0) {
+        orc_rp_canonical_codes(adj, N, code);
+        for (int i = 0; i < N; ++i) len[i] = (uint8_t)adj[i];
+        rc = 0;
+    }
+    free(filt);
+    free(wts);
+    free(l);
+    free(r);
+    free(dep);
+    free(adj);
+    return rc;
+}
+
+/* top_encoder.scala:106 feeds the *sorted* counts to the tree builder, so its codes come out
+ * indexed by rank, while :155-157 index the table by raw symbol; SymbolSort drops the symbol
+ * identities that would connect the two.  Here the identities ride along with the sort and the
+ * codebook is scattered back: table[rank2sym[p]] = codebook_over_ranks[p]. */
+int orc_rp_system_codebook(const uint64_t* freq_by_symbol, int N, int W, uint64_t thr, int lmax,
+                           uint16_t* code, uint8_t* len) {
+    uint64_t* sorted = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)N);
+    uint16_t* ids = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)N);
+    uint16_t* rc_code = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)N);
+    uint8_t* rc_len = (uint8_t*)malloc((size_t)N);
+    orc_aw_symbol_sort(freq_by_symbol, N, sorted, ids);
+    int rc = orc_rp_codebook(sorted, N, W, thr, lmax, rc_code, rc_len);
+    if (rc == 0)
+        for (int p = 0; p < N; ++p) {
+            code[ids[p]] = rc_code[p];
+            len[ids[p]] = rc_len[p];
+        }
+    free(sorted);
+    free(ids);
+    free(rc_code);
+    free(rc_len);
+    return rc;
+}
+
+uint32_t orc_rp_entropy_q16_u64(const uint64_t* freq, int N) {
+    uint64_t total = 0;
+    for (int i = 0; i < N; ++i) total += freq[i];
+    int shift = 0;
+    while ((total >> shift) >> 32) ++shift;
+    uint64_t* f = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)N);
+    for (int i = 0; i < N; ++i) f[i] = freq[i] >> shift;
+    uint32_t e = orc_aw_entropy_q16(f, N, 32);
+    free(f);
+    return e;
+}
+
+/* ---- packed stream ---------------------------------------------------------------------- */
+
+size_t orc_num_chunks(size_t n) { return (n + ORC_CHUNK_SYMS - 1) / ORC_CHUNK_SYMS; }
+
+uint64_t orc_payload_bound_words(size_t n) {
+    /* a lane emits at most ceil(256*16/32) = 128 words of code bits plus one word the
+     * decoder asks for ahead of need */
+    return (uint64_t)orc_num_chunks(n) * ORC_LANES * 129u;
+}
+
+#define LANE_SYMS (ORC_GROUP * ORC_ROUNDS) /* 256 */
+#define PAIR_STEPS (LANE_SYMS / 2)         /* 128 */
+
+uint64_t orc_rp_encode(const uint8_t* sym, size_t n, const uint16_t* code, const uint8_t* len,
+                       uint32_t* payload, uint32_t* chunk_off) {
+    const size_t nchunks = orc_num_chunks(n);
+    uint64_t pos = 0;
+    /* per lane: up to 128 words of bits, pair lengths */
+    uint32_t(*words)[129] = malloc(sizeof(uint32_t[129]) * ORC_LANES);
+    uint8_t(*plen)[PAIR_STEPS] = malloc(sizeof(uint8_t[PAIR_STEPS]) * ORC_LANES);
+    for (size_t c = 0; c < nchunks; ++c) {
+        const size_t base = c * (size_t)ORC_CHUNK_SYMS;
+        const size_t nvalid = n - base < ORC_CHUNK_SYMS ? n - base : ORC_CHUNK_SYMS;
+        unsigned nwords[ORC_LANES];
+        if (chunk_off) chunk_off[c] = (uint32_t)pos;
+        for (unsigned l = 0; l < ORC_LANES; ++l) {
+            uint64_t acc = 0;
+            unsigned accbits = 0, nw = 0;
+            memset(plen[l], 0, PAIR_STEPS);
+            for (unsigned r = 0; r < ORC_ROUNDS; ++r)
+                for (unsigned j = 0; j < ORC_GROUP; ++j) {
+                    size_t i = ((size_t)r * ORC_LANES + l) * ORC_GROUP + j;
+                    if (i >= nvalid) continue;
+                    uint8_t s = sym[base + i];
+                    unsigned L = len[s];
+                    acc = (acc << L) | (uint64_t)(code[s] & ((1u << L) - 1u));
+                    accbits += L;
+                    plen[l][r * 4 + j / 2] = (uint8_t)(plen[l][r * 4 + j / 2] + L);
+                    while (accbits >= 32) {
+                        words[l][nw++] = (uint32_t)(acc >> (accbits - 32));
+                        accbits -= 32;
+                    }
+                }
+            if (accbits) words[l][nw++] = (uint32_t)(acc << (32 - accbits));
+            nwords[l] = nw;
+        }
+        int nb[ORC_LANES];
+        unsigned k[ORC_LANES];
+        for (unsigned l = 0; l < ORC_LANES; ++l) nb[l] = 0, k[l] = 0;
+        for (unsigned t = 0; t < PAIR_STEPS; ++t) {
+            const unsigned r = t / 4, jp = t % 4;
+            for (unsigned l = 0; l < ORC_LANES; ++l) {
+                size_t i0 = ((size_t)r * ORC_LANES + l) * ORC_GROUP + 2 * jp;
+                if (i0 >= nvalid) continue;
+                if (nb[l] < 32) {
+                    uint32_t w = k[l] < nwords[l] ? words[l][k[l]] : 0u;
+                    if (payload) payload[pos] = w;
+                    ++pos;
+                    ++k[l];
+                    nb[l] += 32;
+                }
+                nb[l] -= plen[l][t];
+            }
+        }
+    }
+    if (chunk_off) chunk_off[nchunks] = (uint32_t)pos;
+    free(words);
+    free(plen);
+    return pos;
+}
+
+int orc_rp_decode(const uint32_t* payload, const uint32_t* chunk_off, size_t n,
+                  const uint16_t* code, const uint8_t* len, uint8_t* sym_out) {
+    /* 16-bit prefix table: entry = len << 8 | sym, 0 = no code */
+    uint16_t* tab = (uint16_t*)calloc(65536, sizeof(uint16_t));
+    for (int s = 0; s < 256; ++s) {
+        unsigned L = len[s];
+        if (L == 0 || L > 16) continue;
+        unsigned first = (unsigned)(code[s] & ((1u << L) - 1u)) << (16 - L);
+        for (unsigned e = 0; e < (1u << (16 - L)); ++e) tab[first + e] = (uint16_t)((L << 8) | s);
+    }
+    const size_t nchunks = orc_num_chunks(n);
+    int rc = 0;
+    for (size_t c = 0; c < nchunks && rc == 0; ++c) {
+        const size_t base = c * (size_t)ORC_CHUNK_SYMS;
+        const size_t nvalid = n - base < ORC_CHUNK_SYMS ? n - base : ORC_CHUNK_SYMS;
+        uint64_t win[ORC_LANES];
+        int nb[ORC_LANES];
+        for (unsigned l = 0; l < ORC_LANES; ++l) win[l] = 0, nb[l] = 0;
+        uint64_t pos = chunk_off[c];
+        const uint64_t end = chunk_off[c + 1];
+        for (unsigned t = 0; t < PAIR_STEPS && rc == 0; ++t) {
+            const unsigned r = t / 4, jp = t % 4;
+            for (unsigned l = 0; l < ORC_LANES; ++l) {
+                size_t i0 = ((size_t)r * ORC_LANES + l) * ORC_GROUP + 2 * jp;
+                if (i0 >= nvalid) continue;
+                if (nb[l] < 32) {
+                    if (pos >= end) {
+                        rc = -1;
+                        break;
+                    }
+                    win[l] |= (uint64_t)payload[pos++] << (32 - nb[l]);
+                    nb[l] += 32;
+                }
+                for (unsigned q = 0; q < 2; ++q) {
+                    if (i0 + q >= nvalid) break;
+                    uint16_t e = tab[win[l] >> 48];
+                    unsigned L = e >> 8;
+                    if (L == 0) {
+                        rc = -1;
+                        break;
+                    }
+                    sym_out[base + i0 + q] = (uint8_t)(e & 0xFF);
+                    win[l] <<= L;
+                    nb[l] -= (int)L;
+                }
+                if (rc) break;
+            }
+        }
+        if (rc == 0 && pos != end) rc = -1;
+    }
+    free(tab);
+    return rc;
+}

@@ -1,0 +1,144 @@
+/*
+ * hf_oracle.h -- CPU restatement of the liuyuxivapor/huffman encoder pipeline.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the shipped library links, loads or calls this
+ * file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
+ *
+ * Two layers, kept apart by prefix:
+ *
+ *   orc_aw_*   "as written": literal restatements of the reference modules that are sound
+ *              (SymbolStat, SymbolSort, HuffmanTreeBuilder, the codeStart recurrence, the
+ *              ShannonEntropy/AdaptiveThreshold arithmetic, the encoder lookup mux, the
+ *              TreeQualityAnalyzer arithmetic).  Pinned by the reference's own known-answer
+ *              tests where they exist (t_symbol_stat.scala, t_symbol_sort.scala) and by
+ *              source reading elsewhere.
+ *
+ *   orc_rp_*   "repaired": what the reference intends but does not deliver (true leaf depths,
+ *              a Kraft-correct length limiter, per-symbol canonical codes, the rank->symbol
+ *              permutation, a packed bitstream and a decoder).  PARITY UNPINNED: the reference
+ *              has no working counterpart, so these are pinned only by invariants
+ *              (Kraft, max length, round trip) and by the golden vectors this oracle produced.
+ *
+ * All arithmetic is integer.  "N" is the alphabet size (`depth` / `numLeaves` in the
+ * reference), "W" the counter width (`wtWidth`).
+ */
+#ifndef HF_ORACLE_H
+#define HF_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- stream geometry of the packed format (repaired layer; see orc_rp_encode) ---------- */
+#define ORC_CHUNK_SYMS 16384u /* symbols per chunk = 64 lanes x 256 symbols             */
+#define ORC_LANES 64u
+#define ORC_GROUP 8u          /* consecutive symbols a lane takes per round              */
+#define ORC_ROUNDS 32u        /* rounds per chunk                                        */
+
+enum { ORC_LAYOUT_U8 = 0, ORC_LAYOUT_BF16_EXP = 1, ORC_LAYOUT_FP8 = 2 };
+
+/* ---- front end ------------------------------------------------------------------------- */
+/* Split `n` elements into an 8-bit symbol stream and (BF16_EXP only) a raw side byte stream.
+ * BF16_EXP: symbol = (w >> 7) & 0xFF (the exponent), side = ((w >> 8) & 0x80) | (w & 0x7F).
+ * U8 / FP8: symbol = the byte, no side stream (side may be NULL). */
+void orc_symbolize(const void* data, size_t n, int layout, uint8_t* sym, uint8_t* side);
+void orc_desymbolize(const uint8_t* sym, const uint8_t* side, size_t n, int layout, void* out);
+
+/* ---- as written ------------------------------------------------------------------------ */
+/* SymbolStat (symbol_stat.scala:25-49): freq[sym mod N] += 1, counters wrap at 2^W.
+ * N must be a power of two (the RTL indexes with the low log2(N) bits). */
+void orc_aw_symbol_stat(const uint8_t* sym, size_t n, int N, int W, uint64_t* freq);
+
+/* SymbolSort (symbol_sort.scala:125-142): 2N passes of odd-even transposition, first pass on
+ * odd pairs, swap when a < b (strict) => descending and stable.  `ids` (optional) rides along
+ * with the values: the payload extension that carries symbol identities. */
+void orc_aw_symbol_sort(const uint64_t* in, int N, uint64_t* sorted, uint16_t* ids);
+
+/* HuffmanTreeBuilder (tree_build.scala:47-72, 90-131).  Arrays of 2N-1 entries.
+ * `heights` (optional, 2N-1) is depthArr as the RTL computes it (subtree height); the RTL's
+ * `depths` output is its first N entries, which are never written after init => all zero. */
+void orc_aw_tree_build(const uint64_t* freqs, int N, int W, uint64_t* weights, uint16_t* lefts,
+                       uint16_t* rights, uint16_t* root, uint16_t* heights);
+
+/* codeStart recurrence (entropy_aware_tree_builder.scala:118-127): count[d] over d = 0..16,
+ * codeStart[0] = 0, codeStart[d] = (codeStart[d-1] + count[d-1]) << 1 in 16 bits.
+ * count[0] participates exactly as written. */
+void orc_aw_code_start(const uint16_t* len, int N, uint16_t count[17], uint16_t code_start[17]);
+
+/* The per-symbol code formula exactly as written (entropy_aware_tree_builder.scala:133-155):
+ * code(i) = codeStart[len_i] + prefixSum[len_i].  Not prefix free; kept for the record. */
+void orc_aw_codes_as_written(const uint16_t* len, int N, uint16_t* code);
+
+/* ShannonEntropy (shannon_entropy.scala:52-54, 58-109) with the loop run exactly N times,
+ * W <= 32.  Returns finalEntropy (Q16.16, 32 bits). */
+uint32_t orc_aw_entropy_q16(const uint64_t* freq, int N, int W);
+
+/* AdaptiveThreshold decision (adaptive_threshold.scala:26-28, 65-79): 1 = Huffman, 0 = bypass. */
+int orc_aw_adaptive_mode(uint32_t entropy_q16);
+
+/* EntropyAwareTreeBuilder.sFilter (entropy_aware_tree_builder.scala:61-66). */
+void orc_aw_filter(const uint64_t* freq, int N, uint64_t min_freq_threshold, uint64_t* out);
+
+/* Encoder lookup mux (top_encoder.scala:124-162): one {code,length,mode} triple per symbol.
+ * mode 0 => {sym, sym_width, 0}. out is n entries of 4 bytes: code lo, code hi, length, mode. */
+void orc_aw_encode_pairs(const uint8_t* sym, size_t n, const uint16_t* code, const uint8_t* len,
+                         int mode, int sym_width, uint8_t* out4);
+
+/* TreeQualityAnalyzer (tree_q_analyser.scala:21-47).  Returns 0, or -1 if a divisor is zero
+ * (the RTL result is then undefined). */
+int orc_aw_quality(const uint64_t* freq, const uint8_t* len, int N, int W, uint16_t* avg_len_q8,
+                   uint16_t* efficiency, uint16_t* compression_ratio);
+
+/* ---- repaired -------------------------------------------------------------------------- */
+/* True leaf depths from lefts/rights/root (repairs tree_build.scala:81). */
+void orc_rp_leaf_depths(const uint16_t* lefts, const uint16_t* rights, int root, int N,
+                        uint16_t* depths);
+
+/* Length limiter keeping tree_adjust.scala's four phases (BuildHist, Migrate, FillHoles,
+ * Assign-by-rank, tree_adjust.scala:44-119) with Kraft-correct arithmetic.
+ * Returns the number of Migrate steps taken, or -1 if 2^lmax < N. */
+int orc_rp_tree_adjust(const uint16_t* depths_in, int N, int lmax, uint16_t* depths_out);
+
+/* Canonical codes in index order: code(i) = codeStart[len_i] + #{j < i : len_j == len_i},
+ * count[0] forced to 0 (the intent at entropy_aware_tree_builder.scala:105-111). */
+void orc_rp_canonical_codes(const uint16_t* len, int N, uint16_t* code);
+
+/* EntropyAwareTreeBuilder, repaired, at module level: indices are the caller's indices
+ * (filter -> tree -> depths -> adjust(lmax) -> canonical codes).  Returns 0 / -1. */
+int orc_rp_codebook(const uint64_t* freq, int N, int W, uint64_t min_freq_threshold, int lmax,
+                    uint16_t* code, uint8_t* len);
+
+/* The whole front half of EntropyAwareHuffmanSystem, repaired: per-symbol counts ->
+ * (count desc, symbol asc) sort -> codebook over ranks -> rank->symbol permutation.
+ * Outputs are indexed by raw symbol. */
+int orc_rp_system_codebook(const uint64_t* freq_by_symbol, int N, int W,
+                           uint64_t min_freq_threshold, int lmax, uint16_t* code, uint8_t* len);
+
+/* Entropy for counters wider than 32 bits: if the total needs more than 32 bits every count
+ * is shifted right by the excess first, then orc_aw_entropy_q16(W = 32) applies. */
+uint32_t orc_rp_entropy_q16_u64(const uint64_t* freq, int N);
+
+/* Packed stream.  Chunks of ORC_CHUNK_SYMS symbols; inside a chunk lane l of 64 owns the
+ * symbol groups g = r*64 + l (r = round), 8 symbols each, and concatenates their codes MSB
+ * first into a private bit string cut into 32-bit words.  The chunk payload is those words
+ * of all 64 lanes in the order a lock-step decoder asks for them: before each pair of symbols
+ * every lane holding fewer than 32 buffered bits takes the next word, lanes in ascending order.
+ * chunk_off[c] = first payload word of chunk c, chunk_off[nchunks] = total words.
+ * Returns total words written (payload may be NULL to size only). */
+uint64_t orc_rp_encode(const uint8_t* sym, size_t n, const uint16_t* code, const uint8_t* len,
+                       uint32_t* payload, uint32_t* chunk_off);
+/* Returns 0, or -1 if the payload does not decode (ran past a chunk / no matching code). */
+int orc_rp_decode(const uint32_t* payload, const uint32_t* chunk_off, size_t n,
+                  const uint16_t* code, const uint8_t* len, uint8_t* sym_out);
+
+size_t orc_num_chunks(size_t n);
+/* Upper bound on payload words for n symbols under any codebook with lengths <= 16. */
+uint64_t orc_payload_bound_words(size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

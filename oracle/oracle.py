@@ -1,0 +1,300 @@
+"""ctypes front end of the CPU oracle (oracle/hf_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of bench.py; the shipped package ``huffman_amd`` never imports it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+CHUNK_SYMS = 16384
+LAYOUT_U8, LAYOUT_BF16_EXP, LAYOUT_FP8 = 0, 1, 2
+
+
+def build(force: bool = False) -> str:
+    """Compile liboracle.so with gcc if it is missing or older than its sources."""
+    srcs = [os.path.join(_HERE, f) for f in ("hf_oracle.c", "hf_oracle.h", "Makefile")]
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
+    )
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+_u8p = C.POINTER(C.c_uint8)
+_u16p = C.POINTER(C.c_uint16)
+_u32p = C.POINTER(C.c_uint32)
+_u64p = C.POINTER(C.c_uint64)
+
+
+def _declare(l: C.CDLL) -> None:
+    l.orc_symbolize.argtypes = [C.c_void_p, C.c_size_t, C.c_int, _u8p, _u8p]
+    l.orc_symbolize.restype = None
+    l.orc_desymbolize.argtypes = [_u8p, _u8p, C.c_size_t, C.c_int, C.c_void_p]
+    l.orc_desymbolize.restype = None
+    l.orc_aw_symbol_stat.argtypes = [_u8p, C.c_size_t, C.c_int, C.c_int, _u64p]
+    l.orc_aw_symbol_stat.restype = None
+    l.orc_aw_symbol_sort.argtypes = [_u64p, C.c_int, _u64p, _u16p]
+    l.orc_aw_symbol_sort.restype = None
+    l.orc_aw_tree_build.argtypes = [_u64p, C.c_int, C.c_int, _u64p, _u16p, _u16p, _u16p, _u16p]
+    l.orc_aw_tree_build.restype = None
+    l.orc_aw_code_start.argtypes = [_u16p, C.c_int, _u16p, _u16p]
+    l.orc_aw_code_start.restype = None
+    l.orc_aw_codes_as_written.argtypes = [_u16p, C.c_int, _u16p]
+    l.orc_aw_codes_as_written.restype = None
+    l.orc_aw_entropy_q16.argtypes = [_u64p, C.c_int, C.c_int]
+    l.orc_aw_entropy_q16.restype = C.c_uint32
+    l.orc_aw_adaptive_mode.argtypes = [C.c_uint32]
+    l.orc_aw_adaptive_mode.restype = C.c_int
+    l.orc_aw_filter.argtypes = [_u64p, C.c_int, C.c_uint64, _u64p]
+    l.orc_aw_filter.restype = None
+    l.orc_aw_encode_pairs.argtypes = [_u8p, C.c_size_t, _u16p, _u8p, C.c_int, C.c_int, _u8p]
+    l.orc_aw_encode_pairs.restype = None
+    l.orc_aw_quality.argtypes = [_u64p, _u8p, C.c_int, C.c_int, _u16p, _u16p, _u16p]
+    l.orc_aw_quality.restype = C.c_int
+    l.orc_rp_leaf_depths.argtypes = [_u16p, _u16p, C.c_int, C.c_int, _u16p]
+    l.orc_rp_leaf_depths.restype = None
+    l.orc_rp_tree_adjust.argtypes = [_u16p, C.c_int, C.c_int, _u16p]
+    l.orc_rp_tree_adjust.restype = C.c_int
+    l.orc_rp_canonical_codes.argtypes = [_u16p, C.c_int, _u16p]
+    l.orc_rp_canonical_codes.restype = None
+    l.orc_rp_codebook.argtypes = [_u64p, C.c_int, C.c_int, C.c_uint64, C.c_int, _u16p, _u8p]
+    l.orc_rp_codebook.restype = C.c_int
+    l.orc_rp_system_codebook.argtypes = [_u64p, C.c_int, C.c_int, C.c_uint64, C.c_int, _u16p, _u8p]
+    l.orc_rp_system_codebook.restype = C.c_int
+    l.orc_rp_entropy_q16_u64.argtypes = [_u64p, C.c_int]
+    l.orc_rp_entropy_q16_u64.restype = C.c_uint32
+    l.orc_rp_encode.argtypes = [_u8p, C.c_size_t, _u16p, _u8p, _u32p, _u32p]
+    l.orc_rp_encode.restype = C.c_uint64
+    l.orc_rp_decode.argtypes = [_u32p, _u32p, C.c_size_t, _u16p, _u8p, _u8p]
+    l.orc_rp_decode.restype = C.c_int
+    l.orc_num_chunks.argtypes = [C.c_size_t]
+    l.orc_num_chunks.restype = C.c_size_t
+    l.orc_payload_bound_words.argtypes = [C.c_size_t]
+    l.orc_payload_bound_words.restype = C.c_uint64
+
+
+def _p(a: np.ndarray, t):
+    return a.ctypes.data_as(t)
+
+
+def _arr(x, dt) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(x, dtype=dt))
+
+
+# ---- front end -------------------------------------------------------------------------------
+def symbolize(data: np.ndarray, layout: int):
+    data = np.ascontiguousarray(data)
+    if layout == LAYOUT_BF16_EXP:
+        assert data.dtype == np.uint16
+        n = data.size
+        sym = np.empty(n, np.uint8)
+        side = np.empty(n, np.uint8)
+        lib().orc_symbolize(data.ctypes.data, n, layout, _p(sym, _u8p), _p(side, _u8p))
+        return sym, side
+    assert data.dtype == np.uint8
+    return data.copy(), None
+
+
+def desymbolize(sym: np.ndarray, side, layout: int) -> np.ndarray:
+    sym = _arr(sym, np.uint8)
+    if layout == LAYOUT_BF16_EXP:
+        side = _arr(side, np.uint8)
+        out = np.empty(sym.size, np.uint16)
+        lib().orc_desymbolize(_p(sym, _u8p), _p(side, _u8p), sym.size, layout, out.ctypes.data)
+        return out
+    return sym.copy()
+
+
+# ---- as written -------------------------------------------------------------------------------
+def aw_symbol_stat(sym, N: int = 256, W: int = 32) -> np.ndarray:
+    sym = _arr(sym, np.uint8)
+    freq = np.zeros(N, np.uint64)
+    lib().orc_aw_symbol_stat(_p(sym, _u8p), sym.size, N, W, _p(freq, _u64p))
+    return freq
+
+
+def aw_symbol_sort(freq):
+    freq = _arr(freq, np.uint64)
+    N = freq.size
+    out = np.zeros(N, np.uint64)
+    ids = np.zeros(N, np.uint16)
+    lib().orc_aw_symbol_sort(_p(freq, _u64p), N, _p(out, _u64p), _p(ids, _u16p))
+    return out, ids
+
+
+def aw_tree_build(freqs, W: int = 32):
+    freqs = _arr(freqs, np.uint64)
+    N = freqs.size
+    M = 2 * N - 1
+    weights = np.zeros(M, np.uint64)
+    lefts = np.zeros(M, np.uint16)
+    rights = np.zeros(M, np.uint16)
+    heights = np.zeros(M, np.uint16)
+    root = C.c_uint16(0)
+    lib().orc_aw_tree_build(_p(freqs, _u64p), N, W, _p(weights, _u64p), _p(lefts, _u16p),
+                            _p(rights, _u16p), C.byref(root), _p(heights, _u16p))
+    return dict(weights=weights, lefts=lefts, rights=rights, root=int(root.value), heights=heights)
+
+
+def aw_code_start(lens):
+    lens = _arr(lens, np.uint16)
+    count = np.zeros(17, np.uint16)
+    cs = np.zeros(17, np.uint16)
+    lib().orc_aw_code_start(_p(lens, _u16p), lens.size, _p(count, _u16p), _p(cs, _u16p))
+    return count, cs
+
+
+def aw_codes_as_written(lens) -> np.ndarray:
+    lens = _arr(lens, np.uint16)
+    code = np.zeros(lens.size, np.uint16)
+    lib().orc_aw_codes_as_written(_p(lens, _u16p), lens.size, _p(code, _u16p))
+    return code
+
+
+def aw_entropy_q16(freq, W: int = 32) -> int:
+    freq = _arr(freq, np.uint64)
+    return int(lib().orc_aw_entropy_q16(_p(freq, _u64p), freq.size, W))
+
+
+def aw_adaptive_mode(entropy_q16: int) -> int:
+    return int(lib().orc_aw_adaptive_mode(entropy_q16))
+
+
+def aw_filter(freq, thr: int) -> np.ndarray:
+    freq = _arr(freq, np.uint64)
+    out = np.zeros_like(freq)
+    lib().orc_aw_filter(_p(freq, _u64p), freq.size, thr, _p(out, _u64p))
+    return out
+
+
+def aw_encode_pairs(sym, code, lens, mode: int, sym_width: int = 8) -> np.ndarray:
+    sym = _arr(sym, np.uint8)
+    code = _arr(code, np.uint16)
+    lens = _arr(lens, np.uint8)
+    out = np.zeros((sym.size, 4), np.uint8)
+    lib().orc_aw_encode_pairs(_p(sym, _u8p), sym.size, _p(code, _u16p), _p(lens, _u8p), mode,
+                              sym_width, _p(out, _u8p))
+    return out
+
+
+def aw_quality(freq, lens, W: int = 32):
+    freq = _arr(freq, np.uint64)
+    lens = _arr(lens, np.uint8)
+    a, e, r = C.c_uint16(0), C.c_uint16(0), C.c_uint16(0)
+    rc = lib().orc_aw_quality(_p(freq, _u64p), _p(lens, _u8p), freq.size, W, C.byref(a),
+                              C.byref(e), C.byref(r))
+    if rc != 0:
+        return None
+    return int(a.value), int(e.value), int(r.value)
+
+
+# ---- repaired ---------------------------------------------------------------------------------
+def rp_leaf_depths(lefts, rights, root: int, N: int) -> np.ndarray:
+    lefts = _arr(lefts, np.uint16)
+    rights = _arr(rights, np.uint16)
+    d = np.zeros(N, np.uint16)
+    lib().orc_rp_leaf_depths(_p(lefts, _u16p), _p(rights, _u16p), root, N, _p(d, _u16p))
+    return d
+
+
+def rp_tree_adjust(depths, lmax: int = 16):
+    depths = _arr(depths, np.uint16)
+    out = np.zeros_like(depths)
+    steps = lib().orc_rp_tree_adjust(_p(depths, _u16p), depths.size, lmax, _p(out, _u16p))
+    if steps < 0:
+        raise ValueError("2^lmax < N")
+    return out, int(steps)
+
+
+def rp_canonical_codes(lens) -> np.ndarray:
+    lens = _arr(lens, np.uint16)
+    code = np.zeros(lens.size, np.uint16)
+    lib().orc_rp_canonical_codes(_p(lens, _u16p), lens.size, _p(code, _u16p))
+    return code
+
+
+def rp_codebook(freq, W: int = 64, thr: int = 0, lmax: int = 16):
+    freq = _arr(freq, np.uint64)
+    code = np.zeros(freq.size, np.uint16)
+    lens = np.zeros(freq.size, np.uint8)
+    rc = lib().orc_rp_codebook(_p(freq, _u64p), freq.size, W, thr, lmax, _p(code, _u16p),
+                               _p(lens, _u8p))
+    if rc != 0:
+        raise ValueError("codebook failed")
+    return code, lens
+
+
+def rp_system_codebook(freq_by_symbol, W: int = 64, thr: int = 0, lmax: int = 16):
+    freq = _arr(freq_by_symbol, np.uint64)
+    code = np.zeros(freq.size, np.uint16)
+    lens = np.zeros(freq.size, np.uint8)
+    rc = lib().orc_rp_system_codebook(_p(freq, _u64p), freq.size, W, thr, lmax, _p(code, _u16p),
+                                      _p(lens, _u8p))
+    if rc != 0:
+        raise ValueError("codebook failed")
+    return code, lens
+
+
+def rp_entropy_q16_u64(freq) -> int:
+    freq = _arr(freq, np.uint64)
+    return int(lib().orc_rp_entropy_q16_u64(_p(freq, _u64p), freq.size))
+
+
+def num_chunks(n: int) -> int:
+    return (n + CHUNK_SYMS - 1) // CHUNK_SYMS
+
+
+def payload_bound_words(n: int) -> int:
+    return int(lib().orc_payload_bound_words(n))
+
+
+def rp_encode(sym, code, lens):
+    """Returns (payload words u32, chunk_off u32[nchunks+1])."""
+    sym = _arr(sym, np.uint8)
+    code = _arr(code, np.uint16)
+    lens = _arr(lens, np.uint8)
+    nch = num_chunks(sym.size)
+    off = np.zeros(nch + 1, np.uint32)
+    total = int(lib().orc_rp_encode(_p(sym, _u8p), sym.size, _p(code, _u16p), _p(lens, _u8p),
+                                    None, _p(off, _u32p)))
+    payload = np.zeros(max(total, 1), np.uint32)
+    lib().orc_rp_encode(_p(sym, _u8p), sym.size, _p(code, _u16p), _p(lens, _u8p),
+                        _p(payload, _u32p), _p(off, _u32p))
+    return payload[:total], off
+
+
+def rp_decode(payload, chunk_off, n: int, code, lens) -> np.ndarray:
+    payload = _arr(payload, np.uint32)
+    if payload.size == 0:
+        payload = np.zeros(1, np.uint32)
+    chunk_off = _arr(chunk_off, np.uint32)
+    code = _arr(code, np.uint16)
+    lens = _arr(lens, np.uint8)
+    out = np.zeros(max(n, 1), np.uint8)
+    rc = lib().orc_rp_decode(_p(payload, _u32p), _p(chunk_off, _u32p), n, _p(code, _u16p),
+                             _p(lens, _u8p), _p(out, _u8p))
+    if rc != 0:
+        raise ValueError("payload does not decode")
+    return out[:n]

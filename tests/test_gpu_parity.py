@@ -1,0 +1,360 @@
+"""GPU parity: every C-ABI entry point against the CPU oracle on the same inputs (bit exact).
+
+Known-answer vectors taken from the reference's own specs are marked with their source lines.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import gaussian_bf16, skewed_symbols
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def dev_u8(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint8)).to(DEV)
+
+
+def dev_bf16(a_u16):
+    return torch.from_numpy(np.ascontiguousarray(a_u16).view(np.int16)).to(DEV).view(torch.bfloat16)
+
+
+# ---- SymbolStat ----------------------------------------------------------------------------
+def test_symbol_stat_reference_kat(hf):
+    # t_symbol_stat.scala:14, :28, :48-60 -- SymbolStat(4, 8, 16), inputs 3,3,5,5,5,15
+    out = hf.SymbolStat(sym_width=4, wtWidth=8, depth=16)(dev_u8([3, 3, 5, 5, 5, 15]))
+    exp = np.zeros(16, np.uint64)
+    exp[3], exp[5], exp[15] = 2, 3, 1
+    assert np.array_equal(out, exp)
+
+
+def test_symbol_stat_flush(hf):
+    # t_symbol_stat.scala:64-99 -- count a 1, flush, restart with no data: all zero
+    st = hf.SymbolStat(sym_width=4, wtWidth=8, depth=16)
+    st(dev_u8([1]))
+    st.flush()
+    assert not st(torch.empty(0, dtype=torch.uint8, device=DEV)).any()
+
+
+@pytest.mark.parametrize("n", [0, 1, 15, 16, 17, 4095, 4096, 65537, (1 << 20) + 3])
+@pytest.mark.parametrize("kind", ["uniform", "geometric", "one"])
+def test_symbol_stat_u8_vs_oracle(hf, orc, n, kind):
+    sym = skewed_symbols(n, 11 + n % 7, kind)
+    got = hf.SymbolStat(8, 64, 256)(dev_u8(sym) if n else torch.empty(0, dtype=torch.uint8, device=DEV))
+    assert np.array_equal(got, orc.aw_symbol_stat(sym, 256, 64))
+
+
+def test_symbol_stat_counter_wrap(hf, orc):
+    sym = np.full(1000, 9, np.uint8)
+    got = hf.SymbolStat(8, 8, 256)(dev_u8(sym))
+    assert got[9] == 1000 % 256 and np.array_equal(got, orc.aw_symbol_stat(sym, 256, 8))
+    # N = 16 keeps the low 4 bits of the symbol (symbol_stat.scala:36-37)
+    sym = skewed_symbols(5000, 3, "uniform")
+    assert np.array_equal(hf.SymbolStat(8, 32, 16)(dev_u8(sym)), orc.aw_symbol_stat(sym, 16, 32))
+
+
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 16384, 100003, (1 << 21) + 5])
+def test_symbol_stat_bf16_vs_oracle(hf, orc, n):
+    w = gaussian_bf16(n, seed=n)
+    sym, _ = orc.symbolize(w, orc.LAYOUT_BF16_EXP)
+    got = hf.SymbolStat(8, 64, 256)(dev_bf16(w))
+    assert np.array_equal(got, orc.aw_symbol_stat(sym, 256, 64))
+
+
+# ---- SymbolSort ----------------------------------------------------------------------------
+def test_symbol_sort_reference_kat(hf):
+    # t_symbol_sort.scala:15-16, :46-49 -- SymbolSort(16, 8)
+    inputs = [3, 1, 7, 0, 5, 2, 6, 4, 9, 8, 15, 12, 10, 11, 14, 13]
+    out = hf.SymbolSort(16, 8)(inputs)
+    assert list(out) == sorted(inputs, reverse=True)
+    # t_symbol_sort.scala:92-94 -- all zeros stay all zeros
+    assert not hf.SymbolSort(16, 8)([0] * 16).any()
+
+
+@pytest.mark.parametrize("N", [2, 4, 16, 100, 256])
+def test_symbol_sort_vs_oracle(hf, orc, N):
+    rng = np.random.default_rng(N)
+    for hi in (3, 50, 1 << 40):  # heavy ties, some ties, none
+        f = rng.integers(0, hi, N).astype(np.uint64)
+        srt = hf.SymbolSort(N, 64)
+        out = srt(f)
+        exp, ids = orc.aw_symbol_sort(f)
+        assert np.array_equal(out, exp)
+        assert np.array_equal(srt.rank2sym, ids)
+
+
+# ---- ShannonEntropy / AdaptiveThreshold ----------------------------------------------------
+def test_entropy_vs_oracle(hf, orc):
+    rng = np.random.default_rng(5)
+    cases = []
+    f = np.zeros(256, np.uint64); f[7] = 4096; cases.append(f)          # one symbol
+    cases.append(np.full(256, 16, np.uint64))                            # uniform
+    f = np.zeros(256, np.uint64); f[1] = f[9] = 2048; cases.append(f)    # two symbols
+    cases.append(np.zeros(256, np.uint64))                               # empty block
+    for _ in range(20):
+        cases.append(rng.integers(0, 1 << int(rng.integers(1, 24)), 256).astype(np.uint64))
+    cases.append(rng.integers(0, 1 << 36, 256).astype(np.uint64))        # total above 32 bits
+    for f in cases:
+        e, m = hf.ShannonEntropy(256, 32)(f)
+        exp = orc.rp_entropy_q16_u64(f)
+        assert e == exp
+        assert m == orc.aw_adaptive_mode(exp)
+        if int(f.sum()) < (1 << 32):
+            assert e == orc.aw_entropy_q16(f, 32)
+
+
+# ---- HuffmanTreeBuilder ---------------------------------------------------------------------
+TREE_CASES = [
+    [5, 1, 3, 2],                 # input of t_tree_builder.scala:58
+    [5, 3, 2, 1],
+    [0, 0, 0, 0],                 # input of t_tree_builder.scala:22-24
+    [8, 4, 2, 1, 1, 0, 0, 0],
+    [1] * 8,
+    [13, 8, 5, 3, 2, 1, 1, 0],
+]
+
+
+@pytest.mark.parametrize("freqs", TREE_CASES)
+def test_tree_build_small(hf, orc, freqs):
+    N = len(freqs)
+    t = hf.HuffmanTreeBuilder(N, 32)(freqs)
+    o = orc.aw_tree_build(freqs, 32)
+    for k in ("weights", "lefts", "rights"):
+        assert np.array_equal(t[k], o[k]), k
+    assert t["root"] == o["root"]
+    assert np.array_equal(t["depths"], orc.rp_leaf_depths(o["lefts"], o["rights"], o["root"], N))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_tree_build_256_vs_oracle(hf, orc, seed):
+    rng = np.random.default_rng(seed)
+    hi = [2, 5, 100, 1 << 16, 1 << 30, 1 << 44][seed]
+    f = rng.integers(0, hi, 256).astype(np.uint64)
+    if seed % 2:
+        f = np.sort(f)[::-1].copy()  # as the system feeds it
+    W = 64 if hi > (1 << 20) else 32
+    t = hf.HuffmanTreeBuilder(256, W)(f)
+    o = orc.aw_tree_build(f, W)
+    for k in ("weights", "lefts", "rights"):
+        assert np.array_equal(t[k], o[k]), k
+    assert np.array_equal(t["depths"], orc.rp_leaf_depths(o["lefts"], o["rights"], o["root"], 256))
+
+
+def test_tree_build_refuses_wrapping_weights(hf):
+    f = np.full(256, 1 << 25, np.uint64)  # sum = 2^33 wraps a 32-bit weight
+    with pytest.raises(hf.HuffhipError) as ei:
+        hf.HuffmanTreeBuilder(256, 32)(f)
+    assert ei.value.code == -3
+
+
+# ---- tree_adjust ----------------------------------------------------------------------------
+def fib_counts(k=40, N=256):
+    fib = [1, 1]
+    while len(fib) < k:
+        fib.append(fib[-1] + fib[-2])
+    f = np.zeros(N, np.uint64)
+    f[:k] = fib[::-1]
+    return f
+
+
+def kraft(lens):
+    return sum(2.0 ** -int(l) for l in lens)
+
+
+def test_tree_adjust_vs_oracle(hf, orc):
+    rng = np.random.default_rng(2)
+    cases = []
+    for f in (fib_counts(), np.array([1 << min(30, 255 - i) if i < 31 else 0 for i in range(256)], np.uint64),
+              rng.integers(0, 1000, 256).astype(np.uint64), np.zeros(256, np.uint64)):
+        o = orc.aw_tree_build(f, 64)
+        cases.append(orc.rp_leaf_depths(o["lefts"], o["rights"], o["root"], 256))
+    cases.append(np.arange(1, 257).clip(max=255).astype(np.uint16))  # a 255-deep chain
+    cases.append(np.zeros(256, np.uint16))                            # zeros (the dead depths port)
+    for d in cases:
+        for lmax in (16, 12, 8):
+            got = hf.tree_adjust(256, lmax)(d)
+            exp, _ = orc.rp_tree_adjust(d, lmax)
+            assert np.array_equal(got, exp)
+            assert got.max() <= lmax and kraft(got) <= 1.0 + 1e-12
+            assert np.all(np.diff(got.astype(int)) >= 0)
+    # small N: depths of the 4-leaf tree [1,3,2,3] are re-dealt in index order
+    assert list(hf.tree_adjust(4, 16)([1, 3, 2, 3])) == list(orc.rp_tree_adjust([1, 3, 2, 3], 16)[0])
+
+
+# ---- EntropyAwareTreeBuilder ----------------------------------------------------------------
+@pytest.mark.parametrize("N", [4, 8, 16, 256])
+def test_codebook_module_vs_oracle(hf, orc, N):
+    rng = np.random.default_rng(N)
+    for trial in range(4):
+        f = rng.integers(0, [3, 100, 1 << 20, 1 << 40][trial], N).astype(np.uint64)
+        thr = [0, 1, 50, 0][trial]
+        code, lens = hf.EntropyAwareTreeBuilder(N, 64)(f, min_freq_threshold=thr)
+        ec, el = orc.rp_codebook(f, 64, thr, 16)
+        assert np.array_equal(code, ec) and np.array_equal(lens, el)
+
+
+def test_codebook_length_limit(hf, orc):
+    f = np.sort(fib_counts())[::-1].copy()
+    code, lens = hf.EntropyAwareTreeBuilder(256, 64)(f)
+    ec, el = orc.rp_codebook(f, 64, 0, 16)
+    assert np.array_equal(code, ec) and np.array_equal(lens, el)
+    assert lens.max() == 16 and abs(kraft(lens) - 1.0) < 1e-12
+
+
+# ---- system codebook + encode + decode -------------------------------------------------------
+def system_roundtrip(hf, orc, data_t, sym, mode=1, side=None):
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    s = sys_.encode(data_t, mode=mode)
+    code, lens, m, ent = s.codebook.download()
+    freq = orc.aw_symbol_stat(sym, 256, 64)
+    assert ent == orc.rp_entropy_q16_u64(freq)
+    if mode == hf.HF_MODE_AUTO:
+        assert m == orc.aw_adaptive_mode(ent)
+    if m == 1:
+        ec, el = orc.rp_system_codebook(freq, 64, 0, 16)
+    else:
+        ec, el = np.arange(256, dtype=np.uint16), np.full(256, 8, np.uint8)
+    assert np.array_equal(code, ec) and np.array_equal(lens, el)
+    payload, off = orc.rp_encode(sym, ec, el)
+    nch = orc.num_chunks(sym.size)
+    assert s.total_words == payload.size
+    assert np.array_equal(s.chunk_off[: nch + 1].cpu().numpy().view(np.uint32), off)
+    assert np.array_equal(s.payload[: payload.size].cpu().numpy().view(np.uint32), payload)
+    if side is not None:
+        assert np.array_equal(s.side[: sym.size].cpu().numpy(), side)
+    out = hf.ParrallelHuffmanDecoder().decode(s)
+    assert torch.equal(out.view(torch.int16) if out.dtype == torch.bfloat16 else out,
+                       data_t.view(torch.int16) if data_t.dtype == torch.bfloat16 else data_t)
+    return s
+
+
+def test_config1_4k_uniform(hf, orc):
+    # 4096 symbols, uniform over 0..255, seed 1, Huffman forced
+    sym = np.random.default_rng(1).integers(0, 256, 4096, dtype=np.uint8)
+    s = system_roundtrip(hf, orc, dev_u8(sym), sym, mode=hf.HF_MODE_HUFFMAN)
+    assert s.codebook.download()[2] == 1
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 511, 512, 513, 16383, 16384, 16385, 40000, 3 * 16384 + 77])
+def test_encode_decode_ragged_u8(hf, orc, n):
+    sym = skewed_symbols(n, n, "geometric")
+    system_roundtrip(hf, orc, dev_u8(sym), sym, mode=hf.HF_MODE_HUFFMAN)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "geometric", "one", "two", "fib"])
+@pytest.mark.parametrize("n", [4096, 200000])
+def test_encode_decode_skewed(hf, orc, kind, n):
+    sym = skewed_symbols(n, 17, kind)
+    system_roundtrip(hf, orc, dev_u8(sym), sym, mode=hf.HF_MODE_HUFFMAN)
+
+
+@pytest.mark.parametrize("n", [1, 8, 1000, 16384, 16384 * 5 + 13, 1 << 20])
+def test_encode_decode_bf16(hf, orc, n):
+    w = gaussian_bf16(n, seed=n + 1)
+    sym, side = orc.symbolize(w, orc.LAYOUT_BF16_EXP)
+    system_roundtrip(hf, orc, dev_bf16(w), sym, mode=hf.HF_MODE_HUFFMAN, side=side)
+
+
+def test_empty_stream(hf):
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    s = sys_.encode(torch.empty(0, dtype=torch.uint8, device=DEV), mode=hf.HF_MODE_HUFFMAN)
+    assert s.total_words == 0 and int(s.chunk_off[0]) == 0
+    assert hf.ParrallelHuffmanDecoder().decode(s).numel() == 0
+
+
+def test_bypass_and_auto_modes(hf, orc):
+    sym = skewed_symbols(50000, 4, "uniform")
+    s = system_roundtrip(hf, orc, dev_u8(sym), sym, mode=hf.HF_MODE_BYPASS)
+    assert s.codebook.download()[2] == 0
+    for kind in ("uniform", "one", "geometric"):
+        sym = skewed_symbols(30000, 6, kind)
+        system_roundtrip(hf, orc, dev_u8(sym), sym, mode=hf.HF_MODE_AUTO)
+
+
+def test_encode_pairs_vs_oracle(hf, orc):
+    sym = skewed_symbols(10000, 8, "geometric")
+    d = dev_u8(sym)
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    for mode in (hf.HF_MODE_HUFFMAN, hf.HF_MODE_BYPASS):
+        cb = sys_.codebook(sys_.histogram(d), mode)
+        code, lens, m, _ = cb.download()
+        beats = sys_.encode_pairs(d, cb)
+        exp = orc.aw_encode_pairs(sym, code, lens, m, 8)
+        assert np.array_equal(beats[:, 0], exp[:, 0].astype(np.uint32) | (exp[:, 1].astype(np.uint32) << 8))
+        assert np.array_equal(beats[:, 1], exp[:, 2]) and np.array_equal(beats[:, 2], exp[:, 3])
+
+
+def test_memwrapper_uploaded_codebook(hf, orc):
+    # a valid prefix code that is NOT canonical in symbol order, with codes longer than 12 bits
+    f = np.sort(fib_counts())[::-1].copy()
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(256)
+    code_r, len_r = orc.rp_codebook(f, 64, 0, 16)
+    mw = hf.MemWrapper(256, 16, 8)
+    assert not mw.bulk_read()[2]
+    for r in range(256):
+        mw.write(int(perm[r]), int(code_r[r]), int(len_r[r]))
+    code, lens, ready = mw.bulk_read()
+    assert ready and mw.read(int(perm[0])) == (int(code_r[0]), int(len_r[0]), True)
+    cb = mw.to_device()
+    p = f[np.argsort(perm)].astype(np.float64)  # symbol s has the count of its rank
+    sym = rng.choice(256, 70000, p=p / p.sum()).astype(np.uint8)
+    sym[:256] = np.arange(256)  # every code, including the 16-bit ones, occurs
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    s = sys_.encode_with(dev_u8(sym), cb)
+    payload, off = orc.rp_encode(sym, code, lens)
+    assert s.total_words == payload.size
+    assert np.array_equal(s.payload[: payload.size].cpu().numpy().view(np.uint32), payload)
+    out = hf.ParrallelHuffmanDecoder().decode(s)
+    assert np.array_equal(out.cpu().numpy(), sym)
+
+
+def test_payload_overflow_is_reported(hf):
+    sym = skewed_symbols(100000, 1, "uniform")
+    d = dev_u8(sym)
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    cb = sys_.codebook(sys_.histogram(d), hf.HF_MODE_HUFFMAN)
+    small = torch.empty(1024, dtype=torch.int32, device=DEV)
+    with pytest.raises(hf.HuffhipError) as ei:
+        sys_.encode_with(d, cb, payload=small)
+    assert ei.value.code == -5
+
+
+def test_corrupt_offsets_are_reported(hf):
+    sym = skewed_symbols(50000, 2, "geometric")
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    s = sys_.encode(dev_u8(sym), mode=hf.HF_MODE_HUFFMAN)
+    s.chunk_off[1] = 0x7FFFFFF0  # points far past the payload buffer
+    with pytest.raises(hf.HuffhipError) as ei:
+        hf.ParrallelHuffmanDecoder().decode(s)
+    assert ei.value.code == -7
+
+
+def test_high_entropy_chunks_spill(hf, orc):
+    # a codebook built for one distribution applied to the opposite one: > 8 bits/symbol,
+    # the chunk outgrows the LDS staging area
+    f = np.sort(fib_counts())[::-1].copy()
+    code_r, len_r = orc.rp_codebook(f, 64, 0, 16)
+    mw = hf.MemWrapper()
+    for s_ in range(256):
+        mw.write(s_, int(code_r[s_]), int(len_r[s_]))
+    cb = mw.to_device()
+    sym = np.random.default_rng(9).integers(40, 256, 3 * 16384 + 100, dtype=np.uint8)  # all 16-bit codes
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    bound = int(hf.L.lib().hf_payload_bound_words(sym.size))
+    buf = torch.empty(bound, dtype=torch.int32, device=DEV)
+    s = sys_.encode_with(dev_u8(sym), cb, payload=buf)
+    code, lens, _ = mw.bulk_read()
+    payload, off = orc.rp_encode(sym, code, lens)
+    assert s.total_words == payload.size
+    assert np.array_equal(s.payload[: payload.size].cpu().numpy().view(np.uint32), payload)
+    assert np.array_equal(hf.ParrallelHuffmanDecoder().decode(s).cpu().numpy(), sym)
+
+
+def test_quality_vs_oracle(hf, orc):
+    rng = np.random.default_rng(12)
+    f = rng.integers(0, 5000, 256).astype(np.uint64)
+    _, lens = orc.rp_system_codebook(f, 64, 0, 16)
+    assert hf.TreeQualityAnalyzer(256, 32)(f, lens) == orc.aw_quality(f, lens, 32)
