@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Headline benchmark: exponent-byte Huffman encode + decode of a Llama-3-8B-sized synthetic
+Gaussian bf16 weight stream on MI355X.
+
+One step = one pass of the hot path over the whole tensor, inputs resident in HBM:
+    SymbolStat (histogram) -> [all-reduce of the 256 counts when N > 1: global codebook]
+    -> sort/entropy/tree/adjust/canonical codes -> encode -> decode.
+`value` = uncompressed bytes through that round trip per second, summed over all ranks.
+Run as `python bench.py --gpus 1` or under torch.distributed.run with one rank per GPU.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+LLAMA3_8B_PARAMS = 8_030_261_248
+SLAB = 256 * 1024 * 1024
+HBM_PEAK_GBPS = 8000.0
+
+
+def make_weights(torch, n, device):
+    """fp32 N(0, 0.02^2) -> bf16 (round to nearest even), seed 1234, 256 Mi-element slabs."""
+    g = torch.Generator(device=device)
+    g.manual_seed(1234)
+    out = torch.empty(n, dtype=torch.bfloat16, device=device)
+    for lo in range(0, n, SLAB):
+        hi = min(n, lo + SLAB)
+        slab = torch.randn(hi - lo, generator=g, device=device, dtype=torch.float32)
+        out[lo:hi] = slab.mul_(0.02).to(torch.bfloat16)
+        del slab
+    return out
+
+
+def cpu_baseline(torch, w_gpu, sample_elems):
+    """The CPU oracle (a scalar C restatement of the same pipeline) on a bounded sample."""
+    import numpy as np
+    from oracle import oracle as orc
+    orc.build()
+    m = min(sample_elems, w_gpu.numel())
+    w = w_gpu[:m].view(torch.int16).cpu().numpy().view(np.uint16)
+    t0 = time.perf_counter()
+    sym, side = orc.symbolize(w, orc.LAYOUT_BF16_EXP)
+    freq = orc.aw_symbol_stat(sym, 256, 64)
+    code, lens = orc.rp_system_codebook(freq, 64, 0, 16)
+    t1 = time.perf_counter()
+    payload, off = orc.rp_encode(sym, code, lens)  # sizes, then packs: two passes
+    t2 = time.perf_counter()
+    out = orc.rp_decode(payload, off, m, code, lens)
+    back = orc.desymbolize(out, side, orc.LAYOUT_BF16_EXP)
+    t3 = time.perf_counter()
+    assert np.array_equal(back, w)
+    gb = 2.0 * m / 1e9
+    return {
+        "value": gb / (t3 - t0), "unit": "GB/s", "cores": 1, "kind": "port",
+        "sample": f"first {m} bf16 elements of the same tensor ({gb:.2f} GB), "
+                  "symbolize+histogram+codebook+encode+decode, single thread, gcc -O3",
+        "encode_GBps": gb / (t2 - t0), "decode_GBps": gb / (t3 - t2),
+        "seconds": t3 - t0,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--elems", type=int, default=LLAMA3_8B_PARAMS,
+                    help="bf16 elements per GPU (default: Llama-3-8B parameter count)")
+    ap.add_argument("--cpu-sample", type=int, default=192 * 1024 * 1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from huffman_amd import api as hf
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run, one rank per GPU")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    n = args.elems
+    w = make_weights(torch, n, device)
+    ctx = hf.Context(local_rank)
+    system = hf.EntropyAwareHuffmanSystem(ctx=ctx)
+    decoder = hf.ParrallelHuffmanDecoder(ctx=ctx)
+    stat = hf.SymbolStat(ctx=ctx)
+
+    nch = (n + hf.HF_CHUNK_SYMS - 1) // hf.HF_CHUNK_SYMS
+    freq = torch.zeros(256, dtype=torch.int64, device=device)
+    cb = hf.DeviceCodebook(ctx)
+    side = torch.empty(n, dtype=torch.uint8, device=device)
+    payload = torch.empty(n // 8 + nch * 192 + 64, dtype=torch.int32, device=device)  # 4 bits/sym
+    chunk_off = torch.empty(((nch + 4) // 4) * 4, dtype=torch.int32, device=device)
+    out = torch.empty(n, dtype=torch.bfloat16, device=device)
+
+    def step(ev=None):
+        if ev: ev[0].record()
+        freq.zero_()
+        stat.accumulate(w, freq)
+        if ev: ev[1].record()
+        if world > 1:
+            dist.all_reduce(freq)  # global codebook: identical tables on every rank
+        system.codebook(freq, hf.HF_MODE_HUFFMAN, out=cb)
+        if ev: ev[2].record()
+        s = system.encode_with(w, cb, payload=payload, side=side, chunk_off=chunk_off, sync=False)
+        if ev: ev[3].record()
+        decoder.decode(s, out=out, check_stream=False)
+        if ev: ev[4].record()
+        return s
+
+    for _ in range(args.warmup):
+        s = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        s = step(evs[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel device times (ms), averaged over the timed steps
+    phases = ["hist", "codebook", "encode", "decode"]
+    ms = {p: sum(evs[k][i].elapsed_time(evs[k][i + 1]) for k in range(args.steps)) / args.steps
+          for i, p in enumerate(phases)}
+
+    # ---- outside the timed region: verify and measure the stream -----------------------------
+    ctx.sync()
+    total_words = int(chunk_off[nch].item()) & 0xFFFFFFFF
+    ok = bool(torch.equal(out.view(torch.int16), w.view(torch.int16)))
+    code, lens, mode, ent = cb.download()
+    f = freq.cpu().numpy().astype("float64")
+    bits_ideal = float((f * lens).sum())
+    nsym_codebook = float(f.sum())  # n * world when the histogram was all-reduced
+    lbar = bits_ideal / max(1.0, nsym_codebook)
+    comp_bytes = 4 * total_words + n + 4 * (nch + 1) + 256 * 3
+    ratio = 2.0 * n / comp_bytes
+
+    raw_bytes = 2.0 * n
+    alg = {
+        "hist": 2.0 * n,
+        "encode": n * (2.0 + 1.0 + lbar / 8.0) + 4.0 * nch,
+        "decode": n * (1.0 + lbar / 8.0 + 2.0) + 4.0 * nch,
+    }
+    roof = {}
+    for p in ("hist", "encode", "decode"):
+        ach = alg[p] / (ms[p] * 1e-3) / 1e9
+        roof[p] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                   "frac": ach / HBM_PEAK_GBPS, "traffic": None, "ms": ms[p],
+                   "algorithmic_bytes": alg[p]}
+    dominant = "encode" if ms["encode"] >= ms["decode"] else "decode"
+
+    if rank == 0:
+        line = {
+            "metric": "encode+decode GB/s (uncompressed bf16 bytes through histogram, codebook, "
+                      "encode and decode per second), % HBM roofline, comp. ratio",
+            "value": raw_bytes * world * args.steps / elapsed / 1e9,
+            "unit": "GB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {
+                "workload": ("synthetic Gaussian bf16 weights N(0,0.02^2), "
+                             f"{n} elements per GPU ({raw_bytes / 1e9:.2f} GB), exponent-byte "
+                             "Huffman, forced Huffman mode, Lmax=16, 16384-symbol chunks"
+                             + (", global codebook via RCCL all-reduce of the histogram"
+                                if world > 1 else "")),
+                "elements_per_gpu": n, "chunk_symbols": hf.HF_CHUNK_SYMS,
+            },
+            "encode_GBps": raw_bytes / ((ms["hist"] + ms["codebook"] + ms["encode"]) * 1e-3) / 1e9,
+            "encode_kernel_GBps": raw_bytes / (ms["encode"] * 1e-3) / 1e9,
+            "decode_GBps": raw_bytes / (ms["decode"] * 1e-3) / 1e9,
+            "hist_GBps": raw_bytes / (ms["hist"] * 1e-3) / 1e9,
+            "codebook_ms": ms["codebook"],
+            "compression_ratio": ratio,
+            "bits_per_exponent_ideal": lbar,
+            "bits_per_exponent_stream": 32.0 * total_words / n,
+            "compression_mode": mode, "entropy_q16": ent,
+            "roundtrip_bit_exact": ok,
+            "roofline": dict(roof[dominant], kernel=dominant),
+            "roofline_all": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(torch, w, args.cpu_sample)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("round trip mismatch")
+
+
+if __name__ == "__main__":
+    main()

@@ -31,7 +31,7 @@ constexpr int kSpillWords = kMaxChunkWords - kStgWords;   // global spill per wa
 constexpr u64 kDescAggregate = 1ull << 62;
 constexpr u64 kDescPrefix = 2ull << 62;
 constexpr u64 kDescValueMask = (1ull << 62) - 1ull;
-constexpr uint32_t kSpinLimit = 1u << 24;
+constexpr u64 kSpinTicks = 100000000ull;  // 1 s
 
 // Exclusive prefix (in words) of chunk c over the chunk descriptors.  Lane j inspects the
 // descriptor of chunk idx - j; the nearest descriptor holding an inclusive prefix ends the
@@ -41,6 +41,7 @@ __device__ u64 lookback(const u64* desc, const uint32_t c, const int lane, uint3
     u64 excl = 0;
     long long idx = (long long)c - 1;
     uint32_t spins = 0;
+    u64 t0 = 0;
     while (idx >= 0) {
         const long long j = idx - lane;
         u64 d;
@@ -57,9 +58,14 @@ __device__ u64 lookback(const u64* desc, const uint32_t c, const int lane, uint3
                 if (first_pre < 64) return excl;
                 break;
             }
-            if (++spins > kSpinLimit) {
-                if (lane == 0) atomicOr(err, HF_KERR_TIMEOUT);
-                return excl;
+            // bounded wait: give up after kSpinTicks of the 100 MHz wall clock
+            if ((++spins & 63u) == 0) {
+                const u64 now = __builtin_amdgcn_s_memrealtime();
+                if (t0 == 0) t0 = now;
+                if (now - t0 > kSpinTicks) {
+                    if (lane == 0) atomicOr(err, HF_KERR_TIMEOUT);
+                    return excl;
+                }
             }
             __builtin_amdgcn_s_sleep(2);
         }
@@ -263,35 +269,39 @@ __global__ __launch_bounds__(kWaves * 64) void hf_k_encode(
         if (lane == 0)
             __hip_atomic_store(&desc[c], kDescAggregate | (u64)total, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-        const u64 base = lookback(desc, c, lane, err);
+        // the prefix is the same in every lane: keep it in scalar registers so the branches
+        // below are plain scalar branches
+        const u64 base_v = lookback(desc, c, lane, err);
+        const u64 base = ((u64)__builtin_amdgcn_readfirstlane((uint32_t)(base_v >> 32)) << 32) |
+                         (u64)__builtin_amdgcn_readfirstlane((uint32_t)base_v);
         if (lane == 0) {
             __hip_atomic_store(&desc[c], kDescPrefix | (base + total), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
             chunk_off[c] = (uint32_t)base;
             if (c == nchunks - 1) chunk_off[nchunks] = (uint32_t)(base + total);
         }
-        if (base + total > cap_words || base + total > 0xFFFFFFFFull) {
-            if (lane == 0) atomicOr(err, HF_KERR_OVERFLOW);
-        } else {
-            // LDS writes of all lanes are complete before any lane reads them back
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const uint32_t in_lds = total < (uint32_t)kStgWords ? total : (uint32_t)kStgWords;
-            uint32_t* dst = payload + base;
-            for (uint32_t i = lane; i < in_lds; i += 64) dst[i] = stg[i];
-            if (total > (uint32_t)kStgWords) {
-                // the spill words were written by other lanes of this wavefront: drain the
-                // stores, then read them past the vector L1
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                for (uint32_t i = kStgWords + lane; i < total; i += 64)
-                    dst[i] = __hip_atomic_load(&spill[i - kStgWords], __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+        const bool fits = base + total <= cap_words && base + total <= 0xFFFFFFFFull;
+        if (!fits && lane == 0) atomicOr(err, HF_KERR_OVERFLOW);
+        // LDS writes of all lanes are complete before any lane reads them back
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t ncopy = fits ? total : 0u;  // nothing is written past the buffer
+        const uint32_t in_lds = ncopy < (uint32_t)kStgWords ? ncopy : (uint32_t)kStgWords;
+        uint32_t* dst = payload + base;
+        for (uint32_t i = lane; i < in_lds; i += 64) dst[i] = stg[i];
+        if (ncopy > (uint32_t)kStgWords) {
+            // the spill words were written by other lanes of this wavefront: drain the
+            // stores, then read them past the vector L1
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (uint32_t i = kStgWords + lane; i < ncopy; i += 64)
+                dst[i] = __hip_atomic_load(&spill[i - kStgWords], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        // the staging area is reused by this wavefront's next chunk
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
