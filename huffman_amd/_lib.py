@@ -20,7 +20,7 @@ HF_LAYOUT_U8, HF_LAYOUT_BF16_EXP, HF_LAYOUT_FP8 = 0, 1, 2
 HF_CHUNK_SYMS = 16384
 HF_MAX_CODE_LEN = 16
 HF_MODE_BYPASS, HF_MODE_HUFFMAN, HF_MODE_AUTO = 0, 1, 2
-HF_CODEBOOK_DEV_BYTES = 12288
+HF_CODEBOOK_DEV_BYTES = 20480
 
 
 class hf_entropy_config(C.Structure):

@@ -458,6 +458,7 @@ int hf_decode(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
               const void* d_codebook, void* d_out, int check) {
     if (!ctx || !d_codebook || !layout_ok(layout)) return HF_ERR_ARG;
     if (n && (!d_payload || !d_chunk_off || !d_out)) return HF_ERR_ARG;
+    if (n && payload_words < 4) return HF_ERR_ARG;  // the kernel reads the buffer 16 bytes at a time
     const int lay = norm_layout(layout);
     if (lay == HF_LAYOUT_BF16_EXP && n && !d_side) return HF_ERR_ARG;
     if (!aligned16(d_payload) || !aligned16(d_side) || !aligned16(d_out) ||

@@ -400,18 +400,24 @@ __global__ __launch_bounds__(64) void hf_k_system(const u64* __restrict__ freq25
     }
 }
 
-// Decode tables from enc[]: a 2^12-entry first-level table (assembled in LDS, written out
-// once) and the list of symbols whose codes are longer than 12 bits.  One workgroup.
+// Decode tables from enc[], assembled in LDS and written out once.  First level: 2^12 entries
+// indexed by the next 12 bits.  Codes longer than 12 bits share their 12-bit prefix with at most
+// 15 other codes; every distinct prefix gets a 16-entry second-level table indexed by the
+// following 4 bits, and its first-level entry carries that table's number with length 0.
+// Works for any prefix-free code, canonical or not.  One workgroup of 256 threads.
 __global__ __launch_bounds__(256) void hf_k_tables(hf_cb_dev* cb) {
     __shared__ uint16_t lut[HF_LUT_SIZE];
-    __shared__ uint32_t n_long;
+    __shared__ uint16_t sub[256 * 16];
+    __shared__ uint16_t subidx[HF_LUT_SIZE];
+    __shared__ uint32_t cnt[256];
     __shared__ uint32_t max_len;
     const int tid = threadIdx.x;
-    if (tid == 0) {
-        n_long = 0;
-        max_len = 0;
+    if (tid == 0) max_len = 0;
+    for (int i = tid; i < HF_LUT_SIZE; i += 256) {
+        lut[i] = 0;
+        sub[i] = 0;
+        subidx[i] = 0xFFFFu;
     }
-    for (int i = tid; i < HF_LUT_SIZE; i += 256) lut[i] = 0;
     __syncthreads();
     for (int s = 0; s < 256; ++s) {
         const uint32_t e = cb->enc[s];
@@ -423,19 +429,46 @@ __global__ __launch_bounds__(256) void hf_k_tables(hf_cb_dev* cb) {
             for (uint32_t k = tid; k < span; k += 256) lut[first + k] = (uint16_t)((s << 8) | len);
         }
     }
-    {
-        const uint32_t e = cb->enc[tid];
-        const uint32_t len = e >> 16;
-        atomicMax(&max_len, len);
-        if (len > HF_LUT_BITS) {
-            const uint32_t slot = atomicAdd(&n_long, 1u);
-            cb->long_syms[slot] = (uint8_t)tid;
+    const uint32_t my = cb->enc[tid];
+    const uint32_t my_len = my >> 16;
+    const uint32_t my_code = my & 0xFFFFu;
+    const bool is_long = my_len > HF_LUT_BITS && my_len <= HF_MAX_CODE_LEN;
+    const uint32_t my_prefix = is_long ? (my_code >> (my_len - HF_LUT_BITS)) & (HF_LUT_SIZE - 1) : 0;
+    atomicMax(&max_len, my_len);
+    if (is_long) subidx[my_prefix] = 0;  // mark (every writer stores the same value)
+    __syncthreads();
+    // number the marked prefixes in ascending order: thread t owns entries 16t .. 16t+15
+    uint32_t c = 0;
+    for (int k = 0; k < 16; ++k) c += (subidx[tid * 16 + k] == 0);
+    cnt[tid] = c;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int t = 0; t < tid; ++t) base += cnt[t];
+    for (int k = 0; k < 16; ++k) {
+        const int i = tid * 16 + k;
+        if (subidx[i] == 0) {
+            subidx[i] = (uint16_t)base;
+            lut[i] = (uint16_t)(base << 8);  // length 0 = escape to table `base`
+            ++base;
         }
     }
     __syncthreads();
-    for (int i = tid; i < HF_LUT_SIZE; i += 256) cb->lut[i] = lut[i];
+    if (is_long) {
+        const uint32_t rem = my_len - HF_LUT_BITS;  // 1 .. 4 bits beyond the prefix
+        const uint32_t first = (my_code & ((1u << rem) - 1u)) << (4 - rem);
+        const uint32_t span = 1u << (4 - rem);
+        const uint32_t t = subidx[my_prefix];
+        for (uint32_t k = 0; k < span; ++k) sub[t * 16 + first + k] = (uint16_t)((tid << 8) | my_len);
+    }
+    __syncthreads();
+    uint32_t n_sub = 0;
+    for (int t = 0; t < 256; ++t) n_sub += cnt[t];
+    for (int i = tid; i < HF_LUT_SIZE; i += 256) {
+        cb->lut[i] = lut[i];
+        cb->sub[i] = sub[i];
+    }
     if (tid == 0) {
-        cb->n_long = n_long;
+        cb->n_sub = n_sub;
         cb->max_len = max_len;
     }
 }

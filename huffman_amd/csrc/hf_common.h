@@ -16,11 +16,13 @@
 // Device-resident codebook (HF_CODEBOOK_DEV_BYTES reserves room for it).
 struct hf_cb_dev {
     uint32_t enc[256];           // code | len << 16, by raw symbol
-    uint16_t lut[HF_LUT_SIZE];   // sym << 8 | len for codes of <= HF_LUT_BITS bits, 0 = escape
+    uint16_t lut[HF_LUT_SIZE];   // sym << 8 | len for codes of <= HF_LUT_BITS bits;
+                                 // len == 0: escape, the sym field selects a second-level table
+    uint16_t sub[256 * 16];      // second level: 16 entries per distinct 12-bit prefix of a
+                                 // longer code, indexed by the next 4 bits; sym << 8 | len
     uint16_t code[256];
     uint8_t len[256];
-    uint8_t long_syms[256];      // symbols whose code is longer than HF_LUT_BITS
-    uint32_t n_long;
+    uint32_t n_sub;              // second-level tables in use
     uint32_t mode;               // HF_MODE_BYPASS / HF_MODE_HUFFMAN actually in force
     uint32_t entropy_q16;
     uint32_t entropy_mode;       // what the entropy decision alone says

@@ -56,7 +56,7 @@ typedef struct hf_ctx hf_ctx;
 
 /* Device-resident codebook: encoder table, decoder lookup tables, mode.  Opaque; size and
  * alignment are fixed so callers can place it in their own device allocations. */
-#define HF_CODEBOOK_DEV_BYTES 12288u
+#define HF_CODEBOOK_DEV_BYTES 20480u
 
 /* entropy_config bundle of EntropyAwareTreeBuilder (entropy_aware_tree_builder.scala:9-13).
  * As in the RTL only min_freq_threshold is honoured by the tree stage; tree_depth_limit = 0
@@ -169,9 +169,9 @@ uint64_t hf_num_chunks(uint64_t n);
 uint64_t hf_payload_bound_words(uint64_t n);
 
 /* ---- ParrallelHuffmanDecoder (decoder/top_decoder.scala:6-10, constructor only) ------------ */
-/* Rebuilds n elements of `layout` into d_out.  payload_words = size of the d_payload buffer
- * (offsets pointing past it are reported, never followed).  `check` != 0: synchronise and
- * report in-kernel errors. */
+/* Rebuilds n elements of `layout` into d_out.  payload_words = size of the d_payload buffer,
+ * at least 4 (offsets pointing past it are reported, never followed).  `check` != 0:
+ * synchronise and report in-kernel errors. */
 int hf_decode(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
               const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n, int layout,
               const void* d_codebook, void* d_out, int check);
