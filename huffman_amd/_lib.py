@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhuffhip.so")
+# HUFFHIP_LIB selects another build of the same library (kernel experiments)
+LIB_PATH = os.environ.get("HUFFHIP_LIB") or os.path.join(_HERE, "lib", "libhuffhip.so")
 
 # ---- constants mirrored from include/huffhip.h ------------------------------------------------
 HF_ABI_VERSION = 1

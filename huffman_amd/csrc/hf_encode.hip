@@ -11,10 +11,11 @@
 // order.  The encoder replays that schedule from the code lengths alone, so each word's slot
 // is known before its bits are complete (never more than two slots are pending per lane).
 //
-// A chunk's words are staged in LDS, its size is published in a descriptor, and a decoupled
-// look-back over the earlier descriptors yields its place in the payload; the staged words
-// then leave with coalesced stores.  Chunks are handed out through an atomic ticket so a
-// chunk only ever waits for chunks whose wavefronts are already running.
+// A chunk's words are staged in LDS.  The kWaves chunks a workgroup encodes side by side form a
+// tile; the tile's size is published in a descriptor, a decoupled look-back over the earlier
+// descriptors yields its place in the payload, and the staged words then leave with coalesced
+// stores.  Tiles are handed out through an atomic ticket so a tile only ever waits for tiles
+// whose workgroups are already running.
 //
 // HBM traffic per bf16 element: 2 B read, 1 B side stream written, ~L/8 B payload written.
 #include "hf_common.h"
@@ -33,29 +34,40 @@ constexpr u64 kDescPrefix = 2ull << 62;
 constexpr u64 kDescValueMask = (1ull << 62) - 1ull;
 constexpr u64 kSpinTicks = 100000000ull;  // 1 s
 
-// Exclusive prefix (in words) of chunk c over the chunk descriptors.  Lane j inspects the
-// descriptor of chunk idx - j; the nearest descriptor holding an inclusive prefix ends the
-// walk.  A descriptor is one 8-byte {status, value} word written by a single agent-scope
-// store, so a reader never needs more than the word itself.
-__device__ u64 lookback(const u64* desc, const uint32_t c, const int lane, uint32_t* err) {
+// Exclusive prefix (in words) of tile t over the tile descriptors.  Each pass inspects the 128
+// tiles before the current position, two per lane (lane j: idx - j and idx - 64 - j); the
+// nearest descriptor holding an inclusive prefix ends the walk.  A descriptor is one 8-byte
+// {status, value} word written by a single agent-scope store, so a reader never needs more
+// than the word itself.
+__device__ u64 lookback(const u64* desc, const uint32_t t, const int lane, uint32_t* err) {
     u64 excl = 0;
-    long long idx = (long long)c - 1;
+    long long idx = (long long)t - 1;
     uint32_t spins = 0;
     u64 t0 = 0;
     while (idx >= 0) {
-        const long long j = idx - lane;
-        u64 d;
+        const long long j0 = idx - lane, j1 = idx - 64 - lane;
         for (;;) {
-            d = j >= 0 ? __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                       : kDescPrefix;  // before chunk 0: prefix 0
-            const u64 m_inv = __ballot((d >> 62) == 0);
-            const u64 m_pre = __ballot((d >> 62) == 2);
-            const int first_pre = m_pre ? (int)__builtin_ctzll(m_pre) : 64;
-            const u64 upto = first_pre >= 63 ? ~0ull : ((2ull << first_pre) - 1ull);
-            if ((m_inv & upto) == 0) {
-                const u64 v = (lane <= first_pre) ? (d & kDescValueMask) : 0ull;
+            // before tile 0: prefix 0
+            const u64 d0 = j0 >= 0 ? __hip_atomic_load(&desc[j0], __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT)
+                                   : kDescPrefix;
+            const u64 d1 = j1 >= 0 ? __hip_atomic_load(&desc[j1], __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT)
+                                   : kDescPrefix;
+            const u64 inv0 = __ballot((d0 >> 62) == 0), pre0 = __ballot((d0 >> 62) == 2);
+            const u64 inv1 = __ballot((d1 >> 62) == 0), pre1 = __ballot((d1 >> 62) == 2);
+            // position of the nearest prefix among the 128 (128 = none)
+            const int first = pre0 ? (int)__builtin_ctzll(pre0)
+                                   : (pre1 ? 64 + (int)__builtin_ctzll(pre1) : 128);
+            const int f0 = first < 63 ? first : 63;           // last near lane that counts
+            const int f1 = first < 64 ? -1 : (first - 64 < 63 ? first - 64 : 63);
+            const u64 upto0 = f0 >= 63 ? ~0ull : ((2ull << f0) - 1ull);
+            const u64 upto1 = f1 < 0 ? 0ull : (f1 >= 63 ? ~0ull : ((2ull << f1) - 1ull));
+            if (((inv0 & upto0) | (inv1 & upto1)) == 0) {
+                u64 v = lane <= f0 ? (d0 & kDescValueMask) : 0ull;
+                v += lane <= f1 ? (d1 & kDescValueMask) : 0ull;
                 excl += hf_wave_sum_u64(v);
-                if (first_pre < 64) return excl;
+                if (first < 128) return excl;
                 break;
             }
             // bounded wait: give up after kSpinTicks of the 100 MHz wall clock
@@ -67,9 +79,9 @@ __device__ u64 lookback(const u64* desc, const uint32_t c, const int lane, uint3
                     return excl;
                 }
             }
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(1);
         }
-        idx -= 64;
+        idx -= 128;
     }
     return excl;
 }
@@ -111,123 +123,144 @@ __device__ __forceinline__ void load_group(const void* chunk_in, const uint32_t 
     }
 }
 
+// Per-lane packing state of one chunk.
+struct LaneState {
+    u64 acc = 0;          // code bits not yet emitted, LSB aligned
+    uint32_t ab = 0;      // valid bits in acc (< 32 between pairs)
+    int nb = 0;           // bits the decoder holds for this lane; nb + ab = 32 * (pending slots)
+    uint32_t p0 = 0, p1 = 0;  // slots of the words asked for but not yet complete (at most 2)
+    uint32_t pos = 0;     // next free slot of the chunk (wave-uniform)
+};
+
+// Lanes with `done` place word `w` in slot `slot`.  The LDS path is a plain predicated
+// ds_write; the global spill area is only touched under a wave-uniform branch, so the common
+// path carries no pointer selection.
+__device__ __forceinline__ void put_word(const bool done, const uint32_t slot, const uint32_t w,
+                                         uint32_t* __restrict__ stg, uint32_t* __restrict__ spill) {
+    const bool in_lds = slot < (uint32_t)kStgWords;
+    if (done && in_lds) stg[slot] = w;
+    if (__builtin_expect(__any(done && !in_lds), 0)) {
+        if (done && !in_lds) spill[slot - kStgWords] = w;
+    }
+}
+
+// One round of one lane: 8 symbols out of `raw`, side bytes stored, codes looked up, the
+// decoder's refill schedule replayed and completed words placed.
+template <int LAYOUT, bool FULL>
+__device__ __forceinline__ void encode_round(const uint32_t (&raw)[4], const uint32_t g,
+                                             const uint32_t nvalid, LaneState& st,
+                                             const uint32_t* __restrict__ enc,
+                                             uint32_t* __restrict__ stg,
+                                             uint32_t* __restrict__ spill, uint8_t* side_chunk) {
+    uint32_t s[8];
+    if (LAYOUT == HF_LAYOUT_BF16_EXP) {
+        uint32_t t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t d = raw[i];
+            s[2 * i] = (d >> 7) & 0xFFu;
+            s[2 * i + 1] = (d >> 23) & 0xFFu;
+            // both side bytes of the dword at once: sign bit into bit 7, mantissa below it;
+            // they land in bytes 0 and 2 of t
+            t[i] = ((d >> 8) & 0x00800080u) | (d & 0x007F007Fu);
+        }
+        // gather bytes 0 and 2 of two dwords into one (v_perm_b32)
+        uint32_t sd[2];
+        sd[0] = __builtin_amdgcn_perm(t[1], t[0], 0x06040200u);
+        sd[1] = __builtin_amdgcn_perm(t[3], t[2], 0x06040200u);
+        if (FULL || (g * 8 + 8 <= nvalid)) {
+            reinterpret_cast<uint2*>(side_chunk)[g] = make_uint2(sd[0], sd[1]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (g * 8 + i < nvalid)
+                    side_chunk[(size_t)g * 8 + i] = (uint8_t)(sd[i >> 2] >> (8 * (i & 3)));
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[i] = (raw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+    }
+
+    uint32_t e[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = enc[s[i]];
+
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp) {
+        uint32_t ea = e[2 * jp], eb = e[2 * jp + 1];
+        bool active = true;
+        if (!FULL) {
+            const uint32_t i0 = g * 8 + 2 * jp;
+            active = i0 < nvalid;
+            if (!active) ea = 0;
+            if (i0 + 1 >= nvalid) eb = 0;
+        }
+        const uint32_t la = ea >> 16, lb = eb >> 16;
+        const uint32_t cl = la + lb;
+        const uint32_t comb = ((ea & 0xFFFFu) << lb) | (eb & 0xFFFFu);
+
+        // the decoder's refill schedule: a lane asks for a word when it holds < 32 bits
+        const bool need = active && st.nb < 32;
+        const u64 m = __ballot(need);
+        const uint32_t p = st.pos + hf_mbcnt(m);
+        const bool empty = (st.nb + (int)st.ab) == 0;  // no slot pending
+        st.p1 = need ? p : st.p1;                      // the newest slot
+        st.p0 = (need && empty) ? p : st.p0;           // the oldest slot
+        st.nb += (need ? 32 : 0) - (int)cl;
+        st.pos += (uint32_t)__popcll(m);
+
+        // pack: append the pair, emit the oldest pending word once 32 bits are complete
+        st.acc = (st.acc << cl) | (u64)comb;
+        st.ab += cl;
+        const bool done = st.ab >= 32;
+        put_word(done, st.p0, (uint32_t)(st.acc >> (st.ab & 31u)), stg, spill);
+        st.p0 = done ? st.p1 : st.p0;
+        st.ab &= 31u;
+    }
+}
+
 // One chunk.  Returns the number of payload words (wave-uniform).
 template <int LAYOUT, bool FULL>
 __device__ uint32_t encode_chunk(const void* chunk_in, const uint32_t nvalid,
                                  const uint32_t* __restrict__ enc, uint32_t* __restrict__ stg,
                                  uint32_t* __restrict__ spill, uint8_t* side_chunk,
                                  const int lane) {
-    u64 acc = 0;          // code bits not yet emitted, LSB aligned
-    uint32_t ab = 0;      // valid bits in acc (< 32 between pairs)
-    int nb = 0;           // bits the decoder holds for this lane
-    uint32_t p0 = 0, p1 = 0, fc = 0;  // slots of the words asked for but not yet complete
-    uint32_t pos = 0;     // next free slot of the chunk (wave-uniform)
-
-    const uint32_t rounds = FULL ? HF_ROUNDS : (nvalid + 511u) / 512u;
-    uint32_t cur[4], nxt[4];
-    load_group<LAYOUT, FULL>(chunk_in, (uint32_t)lane, nvalid, cur);
-    if (rounds > 1)
-        load_group<LAYOUT, FULL>(chunk_in, 64u + lane, nvalid, nxt);
-    else
-        nxt[0] = nxt[1] = nxt[2] = nxt[3] = 0;
-
-    for (uint32_t r = 0; r < rounds; ++r) {
-        const uint32_t g = r * 64u + lane;
-        uint32_t nn[4] = {0, 0, 0, 0};
-        if (r + 2 < rounds) load_group<LAYOUT, FULL>(chunk_in, g + 128u, nvalid, nn);
-
-        uint32_t s[8];
-        if (LAYOUT == HF_LAYOUT_BF16_EXP) {
-            uint32_t sd[2] = {0, 0};
+    LaneState st;
+    if (FULL) {
+        // Input groups are fetched kDepth rounds ahead into kDepth named register sets; a set
+        // is refilled right after its symbols are extracted, so no register is copied and the
+        // compiler's waits stay counted.  With two wavefronts per SIMD this depth is what keeps
+        // enough bytes in flight to cover HBM latency.
+        constexpr int kDepth = 8;
+        uint32_t buf[kDepth][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t d = cur[i];
-                s[2 * i] = (d >> 7) & 0xFFu;
-                s[2 * i + 1] = (d >> 23) & 0xFFu;
-                const uint32_t b0 = ((d >> 8) & 0x80u) | (d & 0x7Fu);
-                const uint32_t b1 = ((d >> 24) & 0x80u) | ((d >> 16) & 0x7Fu);
-                sd[i >> 1] |= (b0 | (b1 << 8)) << (16 * (i & 1));
+        for (int d = 0; d < kDepth; ++d)
+            load_group<LAYOUT, true>(chunk_in, (uint32_t)(d * 64 + lane), nvalid, buf[d]);
+        for (uint32_t r0 = 0; r0 < HF_ROUNDS; r0 += kDepth) {
+#pragma unroll
+            for (int d = 0; d < kDepth; ++d) {
+                const uint32_t g = (r0 + d) * 64u + lane;
+                uint32_t raw[4] = {buf[d][0], buf[d][1], buf[d][2], buf[d][3]};
+                // refill this set for round r + kDepth (the last rounds re-read their own group)
+                const uint32_t gn = r0 + d + kDepth < HF_ROUNDS ? g + kDepth * 64u : g;
+                load_group<LAYOUT, true>(chunk_in, gn, nvalid, buf[d]);
+                encode_round<LAYOUT, true>(raw, g, nvalid, st, enc, stg, spill, side_chunk);
             }
-            if (FULL || (g * 8 + 8 <= nvalid)) {
-                reinterpret_cast<uint2*>(side_chunk)[g] = make_uint2(sd[0], sd[1]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    if (g * 8 + i < nvalid)
-                        side_chunk[(size_t)g * 8 + i] = (uint8_t)(sd[i >> 2] >> (8 * (i & 3)));
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) s[i] = (cur[i >> 2] >> (8 * (i & 3))) & 0xFFu;
         }
-
-        uint32_t e[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) e[i] = enc[s[i]];
-
-#pragma unroll
-        for (int jp = 0; jp < 4; ++jp) {
-            uint32_t ea = e[2 * jp], eb = e[2 * jp + 1];
-            bool active = true;
-            if (!FULL) {
-                const uint32_t i0 = g * 8 + 2 * jp;
-                active = i0 < nvalid;
-                if (!active) ea = 0;
-                if (i0 + 1 >= nvalid) eb = 0;
-            }
-            const uint32_t la = ea >> 16, lb = eb >> 16;
-            const uint32_t cl = la + lb;
-            const uint32_t comb = ((ea & 0xFFFFu) << lb) | (eb & 0xFFFFu);
-
-            // the decoder's refill schedule
-            const bool need = active && nb < 32;
-            const u64 m = __ballot(need);
-            const uint32_t p = pos + hf_mbcnt(m);
-            p0 = (need && fc == 0) ? p : p0;
-            p1 = (need && fc != 0) ? p : p1;
-            fc += need ? 1u : 0u;
-            nb += need ? 32 : 0;
-            pos += (uint32_t)__popcll(m);
-            nb -= (int)cl;
-
-            // pack
-            acc = (acc << cl) | (u64)comb;
-            ab += cl;
-            const bool done = ab >= 32;
-            if (done) {
-                const uint32_t w = (uint32_t)(acc >> (ab - 32));
-                if (p0 < (uint32_t)kStgWords)
-                    stg[p0] = w;
-                else
-                    spill[p0 - kStgWords] = w;
-            }
-            p0 = done ? p1 : p0;
-            fc -= done ? 1u : 0u;
-            ab -= done ? 32u : 0u;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            cur[i] = nxt[i];
-            nxt[i] = nn[i];
+    } else {
+        const uint32_t rounds = (nvalid + 511u) / 512u;
+        for (uint32_t r = 0; r < rounds; ++r) {
+            const uint32_t g = r * 64u + lane;
+            uint32_t raw[4];
+            load_group<LAYOUT, false>(chunk_in, g, nvalid, raw);
+            encode_round<LAYOUT, false>(raw, g, nvalid, st, enc, stg, spill, side_chunk);
         }
     }
     // words asked for but not filled: the zero-padded last word, then an all-zero word
-    if (fc > 0) {
-        const uint32_t w = (uint32_t)(acc << (32 - ab));
-        if (p0 < (uint32_t)kStgWords)
-            stg[p0] = w;
-        else
-            spill[p0 - kStgWords] = w;
-        p0 = p1;
-        fc -= 1;
-    }
-    if (fc > 0) {
-        if (p0 < (uint32_t)kStgWords)
-            stg[p0] = 0;
-        else
-            spill[p0 - kStgWords] = 0;
-    }
-    return pos;
+    const uint32_t pending = (uint32_t)(st.nb + (int)st.ab) >> 5;  // 0, 1 or 2 slots
+    put_word(pending > 0, st.p0, (uint32_t)(st.acc << (32 - st.ab)), stg, spill);
+    put_word(pending > 1, st.p1, 0u, stg, spill);
+    return st.pos;
 }
 
 template <int LAYOUT>
@@ -238,8 +271,10 @@ __global__ __launch_bounds__(kWaves * 64) void hf_k_encode(
     uint32_t* spill_base, uint32_t* err) {
     __shared__ uint32_t enc[256];
     __shared__ uint32_t stg_all[kWaves][kStgWords];
+    __shared__ uint32_t tile_ticket;
+    __shared__ uint32_t tile_tot[kWaves];
+    __shared__ u64 tile_base;
     enc[threadIdx.x] = cb->enc[threadIdx.x];
-    __syncthreads();
 
     const int lane = hf_lane();
     const int wave = threadIdx.x >> 6;
@@ -247,61 +282,89 @@ __global__ __launch_bounds__(kWaves * 64) void hf_k_encode(
     uint32_t* spill = spill_base + ((size_t)blockIdx.x * kWaves + wave) * kSpillWords;
     const size_t elem_bytes = LAYOUT == HF_LAYOUT_BF16_EXP ? 2 : 1;
 
+    // A tile is kWaves consecutive chunks, one per wavefront of the workgroup.  Tiles are handed
+    // out through an atomic ticket, so a tile only ever waits for tiles already running.  The
+    // chunk sizes of a tile are summed through LDS and ONE wavefront runs the look-back for
+    // the tile: with thousands of chunks in flight that keeps the chain of dependent
+    // descriptor reads short.
     for (;;) {
-        uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(ticket, 1u);
-        const uint32_t c = __builtin_amdgcn_readfirstlane(t);
-        if (c >= nchunks) break;
+        if (threadIdx.x == 0) tile_ticket = atomicAdd(ticket, 1u);
+        __syncthreads();  // (1) ticket visible; also closes the previous tile's LDS reads
+        const uint32_t t = tile_ticket;
+        if ((uint64_t)t * kWaves >= nchunks) break;
+        const uint32_t c = t * kWaves + wave;
 
-        const uint64_t first = (uint64_t)c * HF_CHUNK_SYMS;
-        const uint64_t left = n - first;
-        const uint32_t nvalid = left < HF_CHUNK_SYMS ? (uint32_t)left : HF_CHUNK_SYMS;
-        const void* chunk_in = reinterpret_cast<const uint8_t*>(data) + first * elem_bytes;
-        uint8_t* side_chunk = side ? side + first : nullptr;
-
-        uint32_t total;
-        if (nvalid == HF_CHUNK_SYMS)
-            total = encode_chunk<LAYOUT, true>(chunk_in, nvalid, enc, stg, spill, side_chunk, lane);
-        else
-            total = encode_chunk<LAYOUT, false>(chunk_in, nvalid, enc, stg, spill, side_chunk, lane);
-        total = __builtin_amdgcn_readfirstlane(total);
-
-        if (lane == 0)
-            __hip_atomic_store(&desc[c], kDescAggregate | (u64)total, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t total = 0;
+        if (c < nchunks) {
+            const uint64_t first = (uint64_t)c * HF_CHUNK_SYMS;
+            const uint64_t left = n - first;
+            const uint32_t nvalid = left < HF_CHUNK_SYMS ? (uint32_t)left : HF_CHUNK_SYMS;
+            const void* chunk_in = reinterpret_cast<const uint8_t*>(data) + first * elem_bytes;
+            uint8_t* side_chunk = side ? side + first : nullptr;
+            if (nvalid == HF_CHUNK_SYMS)
+                total = encode_chunk<LAYOUT, true>(chunk_in, nvalid, enc, stg, spill, side_chunk,
+                                                   lane);
+            else
+                total = encode_chunk<LAYOUT, false>(chunk_in, nvalid, enc, stg, spill, side_chunk,
+                                                    lane);
+            total = __builtin_amdgcn_readfirstlane(total);
+        }
+        if (lane == 0) tile_tot[wave] = total;
+        __syncthreads();  // (2) all chunk sizes of the tile known; staged words visible
+        uint32_t my_off = 0, tile_total = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            const uint32_t x = tile_tot[w];
+            my_off += w < wave ? x : 0u;
+            tile_total += x;
+        }
+        if (wave == 0) {
+            if (lane == 0)
+                __hip_atomic_store(&desc[t], kDescAggregate | (u64)tile_total, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            const u64 b = lookback(desc, t, lane, err);
+            if (lane == 0) {
+                __hip_atomic_store(&desc[t], kDescPrefix | (b + tile_total), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                tile_base = b;
+            }
+        }
+        __syncthreads();  // (3) tile base known
         // the prefix is the same in every lane: keep it in scalar registers so the branches
         // below are plain scalar branches
-        const u64 base_v = lookback(desc, c, lane, err);
-        const u64 base = ((u64)__builtin_amdgcn_readfirstlane((uint32_t)(base_v >> 32)) << 32) |
-                         (u64)__builtin_amdgcn_readfirstlane((uint32_t)base_v);
-        if (lane == 0) {
-            __hip_atomic_store(&desc[c], kDescPrefix | (base + total), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            chunk_off[c] = (uint32_t)base;
-            if (c == nchunks - 1) chunk_off[nchunks] = (uint32_t)(base + total);
+        const u64 tb = tile_base;
+        const u64 base = (((u64)__builtin_amdgcn_readfirstlane((uint32_t)(tb >> 32)) << 32) |
+                          (u64)__builtin_amdgcn_readfirstlane((uint32_t)tb)) + my_off;
+        if (c < nchunks) {
+            if (lane == 0) {
+                chunk_off[c] = (uint32_t)base;
+                if (c == nchunks - 1) chunk_off[nchunks] = (uint32_t)(base + total);
+            }
+            const bool fits = base + total <= cap_words && base + total <= 0xFFFFFFFFull;
+            if (!fits && lane == 0) atomicOr(err, HF_KERR_OVERFLOW);
+            const uint32_t ncopy = fits ? total : 0u;  // nothing is written past the buffer
+            const uint32_t in_lds = ncopy < (uint32_t)kStgWords ? ncopy : (uint32_t)kStgWords;
+            uint32_t* dst = payload + base;
+            // four LDS reads in flight per lane, then four coalesced 256-byte stores
+            uint32_t i = lane;
+            for (; i + 192 < in_lds; i += 256) {
+                const uint32_t a0 = stg[i], a1 = stg[i + 64], a2 = stg[i + 128], a3 = stg[i + 192];
+                dst[i] = a0;
+                dst[i + 64] = a1;
+                dst[i + 128] = a2;
+                dst[i + 192] = a3;
+            }
+            for (; i < in_lds; i += 64) dst[i] = stg[i];
+            if (ncopy > (uint32_t)kStgWords) {
+                // the spill words were written by other lanes of this wavefront: drain the
+                // stores, then read them past the vector L1
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                for (uint32_t k = kStgWords + lane; k < ncopy; k += 64)
+                    dst[k] = __hip_atomic_load(&spill[k - kStgWords], __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
-        const bool fits = base + total <= cap_words && base + total <= 0xFFFFFFFFull;
-        if (!fits && lane == 0) atomicOr(err, HF_KERR_OVERFLOW);
-        // LDS writes of all lanes are complete before any lane reads them back
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const uint32_t ncopy = fits ? total : 0u;  // nothing is written past the buffer
-        const uint32_t in_lds = ncopy < (uint32_t)kStgWords ? ncopy : (uint32_t)kStgWords;
-        uint32_t* dst = payload + base;
-        for (uint32_t i = lane; i < in_lds; i += 64) dst[i] = stg[i];
-        if (ncopy > (uint32_t)kStgWords) {
-            // the spill words were written by other lanes of this wavefront: drain the
-            // stores, then read them past the vector L1
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            for (uint32_t i = kStgWords + lane; i < ncopy; i += 64)
-                dst[i] = __hip_atomic_load(&spill[i - kStgWords], __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        // the staging area is reused by this wavefront's next chunk
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
 }
 

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--elems", type=int, default=1 << 30)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--kinds", default="gauss,uniform,geom,fp8")
+    ap.add_argument("--no-decode", action="store_true", help="skip decode (experimental encoder builds)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     ctx = hf.Context(0)
@@ -53,6 +54,10 @@ def main():
             cb = sysm.codebook(freq, hf.HF_MODE_HUFFMAN)
             s = sysm.encode_with(w, cb)
             t["enc"].append(ctx.last_kernel_ms())
+            if a.no_decode:
+                t["dec"].append(float("nan"))
+                out = w
+                continue
             out = dec.decode(s)
             t["dec"].append(ctx.last_kernel_ms())
         ok = torch.equal(out.view(torch.int16) if eb == 2 else out, w.view(torch.int16) if eb == 2 else w)
