@@ -1,0 +1,105 @@
+"""CPU suite: the C-ABI library loads and exports what include/huffhip.h declares; the
+host-only entry points compute; nothing needs a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "huffhip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import huffman_amd
+    return huffman_amd.lib()
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(hf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported_and_bound(lib):
+    from huffman_amd import _lib
+    names = declared_functions()
+    assert len(names) >= 24
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in huffhip.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_header_constants_match_binding():
+    from huffman_amd import _lib
+    src = open(HEADER).read()
+    for name in ("HF_ABI_VERSION", "HF_CHUNK_SYMS", "HF_MAX_CODE_LEN", "HF_CODEBOOK_DEV_BYTES",
+                 "HF_LAYOUT_U8", "HF_LAYOUT_BF16_EXP", "HF_LAYOUT_FP8", "HF_MODE_BYPASS",
+                 "HF_MODE_HUFFMAN", "HF_MODE_AUTO"):
+        m = re.search(rf"#define\s+{name}\s+\(?(-?\d+)u?\)?", src)
+        assert m, name
+        assert int(m.group(1)) == getattr(_lib, name), name
+    for name in ("HF_ERR_ARG", "HF_ERR_ALIGN", "HF_ERR_RANGE", "HF_ERR_HIP", "HF_ERR_OVERFLOW",
+                 "HF_ERR_TIMEOUT", "HF_ERR_CORRUPT", "HF_ERR_NOMEM"):
+        m = re.search(rf"#define\s+{name}\s+\((-?\d+)\)", src)
+        assert m and int(m.group(1)) == getattr(_lib, name), name
+
+
+def test_host_only_entry_points(lib, orc):
+    assert lib.hf_abi_version() == 1
+    assert lib.hf_error_string(0) == b"ok" and b"aligned" in lib.hf_error_string(-2)
+    for n in (0, 1, 16384, 16385, 10**9):
+        assert lib.hf_num_chunks(n) == orc.num_chunks(n)
+        assert lib.hf_payload_bound_words(n) == orc.payload_bound_words(n)
+
+
+def test_quality_matches_oracle(lib, orc):
+    rng = np.random.default_rng(4)
+    for W in (32, 16, 64):
+        f = rng.integers(0, 3000, 256).astype(np.uint64)
+        _, lens = orc.rp_system_codebook(f, 64, 0, 16)
+        a, e, r = C.c_uint16(0), C.c_uint16(0), C.c_uint16(0)
+        rc = lib.hf_quality(None, f.ctypes.data_as(C.POINTER(C.c_uint64)),
+                            lens.ctypes.data_as(C.POINTER(C.c_uint8)), 256, W, C.byref(a),
+                            C.byref(e), C.byref(r))
+        assert rc == 0
+        assert (a.value, e.value, r.value) == orc.aw_quality(f, lens, W)
+    z = np.zeros(256, np.uint64)
+    rc = lib.hf_quality(None, z.ctypes.data_as(C.POINTER(C.c_uint64)),
+                        lens.ctypes.data_as(C.POINTER(C.c_uint8)), 256, 32, C.byref(a), C.byref(e),
+                        C.byref(r))
+    assert rc == -3  # the RTL divides by zero here
+
+
+def test_argument_checks_need_no_gpu(lib):
+    # null context / null pointers are rejected before any HIP call
+    assert lib.hf_flush(None) == -1
+    assert lib.hf_sync(None) == -1
+    assert lib.hf_symbol_sort(None, None, 256, None, None) == -1
+    assert lib.hf_encode(None, None, 0, 0, None, None, None, 0, None, None) == -1
+    assert lib.hf_decode(None, None, 0, None, None, 0, 0, None, None, 0) == -1
+
+
+def test_no_gpu_means_a_clean_error_not_a_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    assert lib.hf_ctx_create(C.byref(h), 0, None) == -4 and not h.value
+    from huffman_amd import api
+    with pytest.raises(RuntimeError):
+        api.Context()
+
+
+def test_product_sources_never_touch_the_oracle():
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "huffman_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(base, f), errors="ignore").read()
+                if re.search(r"\boracle\b|liboracle|hf_oracle", txt):
+                    bad.append(os.path.join(base, f))
+    assert not bad, bad
