@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--elems", type=int, default=LLAMA3_8B_PARAMS,
                     help="bf16 elements per GPU (default: Llama-3-8B parameter count)")
-    ap.add_argument("--cpu-sample", type=int, default=192 * 1024 * 1024)
+    ap.add_argument("--cpu-sample", type=int, default=1536 * 1024 * 1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
