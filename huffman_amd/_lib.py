@@ -22,6 +22,7 @@ HF_CHUNK_SYMS = 16384
 HF_MAX_CODE_LEN = 16
 HF_MODE_BYPASS, HF_MODE_HUFFMAN, HF_MODE_AUTO = 0, 1, 2
 HF_CODEBOOK_DEV_BYTES = 20480
+HF_CHUNK_CODEBOOK_BYTES = 1552
 
 
 class hf_entropy_config(C.Structure):
@@ -63,6 +64,13 @@ SIGNATURES = {
     "hf_num_chunks": (C.c_uint64, [C.c_uint64]),
     "hf_payload_bound_words": (C.c_uint64, [C.c_uint64]),
     "hf_decode": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, C.c_uint64, C.c_int, _vp, _vp, C.c_int]),
+    "hf_symbol_stat_chunks_dev": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, _vp]),
+    "hf_system_codebook_chunks_dev": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_uint64, _vp]),
+    "hf_encode_chunks": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, _vp, _vp, _vp, C.c_uint64, _vp,
+                                   _u64p]),
+    "hf_decode_chunks": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, C.c_uint64, C.c_int, _vp, _vp,
+                                   C.c_uint64, _vp, C.c_int]),
+    "hf_chunk_codebook_download": (C.c_int, [_vp, _vp, C.c_uint64, _u16p, _u8p, _ip, _u32p]),
     "hf_quality": (C.c_int, [_vp, _u64p, _u8p, C.c_int, C.c_int, _u16p, _u16p, _u16p]),
     "hf_last_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "hf_set_timing": (C.c_int, [_vp, C.c_int]),

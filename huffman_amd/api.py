@@ -324,18 +324,23 @@ class EncodedStream:
     payload: torch.Tensor      # int32 words (capacity may exceed total_words)
     chunk_off: torch.Tensor    # int32[nchunks + 1]
     side: Optional[torch.Tensor]  # uint8[n] for bf16, else None
-    codebook: DeviceCodebook
+    codebook: Optional[DeviceCodebook]
     total_words: Optional[int] = None
+    chunk_codebooks: Optional[torch.Tensor] = None  # per-block codebook records (uint8)
+    chunk_freq: Optional[torch.Tensor] = None       # per-block counts, int32[nchunks * 256]
 
     @property
     def nchunks(self) -> int:
         return (self.n + HF_CHUNK_SYMS - 1) // HF_CHUNK_SYMS
 
     def compressed_bytes(self) -> int:
-        """payload + side stream + chunk offsets + codebook as 256 x (16-bit code, 8-bit len)."""
+        """payload + side stream + chunk offsets + codebooks.  A stream-wide codebook counts as
+        256 x (16-bit code, 8-bit length); a per-block codebook as its canonical order
+        (256 symbol ids + 17 length counts = 273 bytes per block)."""
         assert self.total_words is not None
         side = self.n if self.side is not None else 0
-        return 4 * self.total_words + side + 4 * (self.nchunks + 1) + 256 * 3
+        books = 256 * 3 if self.chunk_codebooks is None else 273 * self.nchunks
+        return 4 * self.total_words + side + 4 * (self.nchunks + 1) + books
 
     def ratio(self) -> float:
         raw = self.n * (2 if self.layout == HF_LAYOUT_BF16_EXP else 1)
@@ -406,6 +411,54 @@ class EntropyAwareHuffmanSystem(_Module):
         cb = self.codebook(freq, mode, min_freq_threshold)
         return self.encode_with(data_in, cb, layout)
 
+    # -- per-block codebooks (one codebook per 16384-symbol chunk, e.g. a KV-cache page) --------
+    def encode_blocks(self, data_in: torch.Tensor, mode: int = HF_MODE_AUTO,
+                      layout: Optional[int] = None, min_freq_threshold: int = 0,
+                      sync: bool = True) -> EncodedStream:
+        """Every chunk is a block of its own: SymbolStat, SymbolSort, the entropy decision and
+        EntropyAwareTreeBuilder run once per chunk, then the chunk is packed with its table."""
+        data_in = data_in.contiguous()
+        lay = layout_of(data_in) if layout is None else layout
+        n = data_in.numel()
+        dev = data_in.device
+        nch = (n + HF_CHUNK_SYMS - 1) // HF_CHUNK_SYMS
+        freq = torch.empty(max(1, nch) * 256, dtype=torch.int32, device=dev)
+        cbs = torch.empty(max(1, nch) * L.HF_CHUNK_CODEBOOK_BYTES, dtype=torch.uint8, device=dev)
+        h = self.ctx.handle
+        check(L.lib().hf_symbol_stat_chunks_dev(h, C.c_void_p(_dev_ptr(data_in)), n, lay,
+                                                C.c_void_p(freq.data_ptr())),
+              "hf_symbol_stat_chunks_dev")
+        check(L.lib().hf_system_codebook_chunks_dev(h, C.c_void_p(freq.data_ptr()), nch, mode,
+                                                    min_freq_threshold, C.c_void_p(cbs.data_ptr())),
+              "hf_system_codebook_chunks_dev")
+        payload = torch.empty(max(4, n // 4 + nch * 192 + 64), dtype=torch.int32, device=dev)
+        chunk_off = torch.empty(((nch + 1 + 3) // 4) * 4, dtype=torch.int32, device=dev)
+        side = torch.empty(max(16, n), dtype=torch.uint8, device=dev) \
+            if lay == HF_LAYOUT_BF16_EXP else None
+        total = C.c_uint64(0)
+        check(L.lib().hf_encode_chunks(h, C.c_void_p(_dev_ptr(data_in)), n, lay,
+                                       C.c_void_p(cbs.data_ptr()), C.c_void_p(_dev_ptr(side)),
+                                       C.c_void_p(payload.data_ptr()), payload.numel(),
+                                       C.c_void_p(chunk_off.data_ptr()),
+                                       C.byref(total) if sync else None), "hf_encode_chunks")
+        return EncodedStream(n=n, layout=lay, dtype=data_in.dtype, payload=payload,
+                             chunk_off=chunk_off, side=side, codebook=None,
+                             total_words=int(total.value) if sync else None,
+                             chunk_codebooks=cbs, chunk_freq=freq)
+
+    def block_codebook(self, s: EncodedStream, chunk: int):
+        """code, length (by symbol), compression_mode and entropy of one block's codebook."""
+        code = np.zeros(256, np.uint16)
+        lens = np.zeros(256, np.uint8)
+        mode = C.c_int(0)
+        ent = C.c_uint32(0)
+        check(L.lib().hf_chunk_codebook_download(self.ctx.handle,
+                                                 C.c_void_p(s.chunk_codebooks.data_ptr()), chunk,
+                                                 _ptr(code, _u16p), _ptr(lens, _u8p),
+                                                 C.byref(mode), C.byref(ent)),
+              "hf_chunk_codebook_download")
+        return code, lens, int(mode.value), int(ent.value)
+
     def encode_pairs(self, data_in: torch.Tensor, cb: DeviceCodebook,
                      layout: Optional[int] = None) -> np.ndarray:
         """``encoded_out`` beats, one per symbol: columns code, length, compression_mode."""
@@ -429,8 +482,32 @@ class ParrallelHuffmanDecoder(_Module):  # spelling as in decoder/top_decoder.sc
         if depth != 256 or symWidth != 8 or maxCodeLen != 16:
             raise ValueError("the packed stream is defined for symWidth=8, depth=256, maxCodeLen=16")
 
+    def decode_blocks(self, s: EncodedStream, chunk_ids: Optional[torch.Tensor] = None,
+                      out: Optional[torch.Tensor] = None, check_stream: bool = True) -> torch.Tensor:
+        """Decode a stream with per-block codebooks.  With ``chunk_ids`` (int32 device tensor)
+        this is decode-on-read: the listed chunks, in that order, land back to back in ``out``."""
+        assert s.chunk_codebooks is not None
+        if chunk_ids is None:
+            n_out, n_ids = s.n, 0
+        else:
+            assert chunk_ids.dtype == torch.int32 and chunk_ids.is_cuda
+            n_ids = chunk_ids.numel()
+            n_out = n_ids * HF_CHUNK_SYMS
+        if out is None:
+            out = torch.empty(max(n_out, 16), dtype=s.dtype, device=s.payload.device)
+        check(L.lib().hf_decode_chunks(self.ctx.handle, C.c_void_p(s.payload.data_ptr()),
+                                       s.payload.numel(), C.c_void_p(s.chunk_off.data_ptr()),
+                                       C.c_void_p(_dev_ptr(s.side)), s.n, s.layout,
+                                       C.c_void_p(s.chunk_codebooks.data_ptr()),
+                                       C.c_void_p(_dev_ptr(chunk_ids)), n_ids,
+                                       C.c_void_p(out.data_ptr()), 1 if check_stream else 0),
+              "hf_decode_chunks")
+        return out[:n_out]
+
     def decode(self, s: EncodedStream, out: Optional[torch.Tensor] = None,
                check_stream: bool = True) -> torch.Tensor:
+        if s.chunk_codebooks is not None:
+            return self.decode_blocks(s, None, out, check_stream)
         if out is None:
             out = torch.empty(max(s.n, 16), dtype=s.dtype, device=s.payload.device)
         check(L.lib().hf_decode(self.ctx.handle, C.c_void_p(s.payload.data_ptr()),

@@ -404,9 +404,10 @@ uint64_t hf_num_chunks(uint64_t n) { return (n + HF_CHUNK_SYMS - 1) / HF_CHUNK_S
 
 uint64_t hf_payload_bound_words(uint64_t n) { return hf_num_chunks(n) * 64ull * 129ull; }
 
-int hf_encode(hf_ctx* ctx, const void* d_data, uint64_t n, int layout, const void* d_codebook,
-              uint8_t* d_side, uint32_t* d_payload, uint64_t payload_cap_words,
-              uint32_t* d_chunk_off, uint64_t* h_total_words) {
+static int encode_common(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
+                         const void* d_codebook, bool per_chunk, uint8_t* d_side,
+                         uint32_t* d_payload, uint64_t payload_cap_words, uint32_t* d_chunk_off,
+                         uint64_t* h_total_words) {
     if (!ctx || !d_codebook || !d_chunk_off || !layout_ok(layout)) return HF_ERR_ARG;
     if (n && (!d_data || !d_payload)) return HF_ERR_ARG;
     const int lay = norm_layout(layout);
@@ -435,9 +436,16 @@ int hf_encode(hf_ctx* ctx, const void* d_data, uint64_t n, int layout, const voi
         HF_HIP(hipMemsetAsync(ctx->d_desc, 0, ((nchunks + 1) & ~1ull) * sizeof(unsigned long long),
                               ctx->stream));
         tic(ctx);
-        hf_launch_encode(d_data, n, lay, reinterpret_cast<const hf_cb_dev*>(d_codebook), d_side,
-                         d_payload, payload_cap_words, d_chunk_off, ctx->d_desc, ctx->d_ctl,
-                         ctx->d_spill, ctx->d_ctl + 1, ctx->num_cu, ctx->stream);
+        if (per_chunk)
+            hf_launch_encode_chunks(d_data, n, lay,
+                                    reinterpret_cast<const hf_chunk_cb*>(d_codebook), d_side,
+                                    d_payload, payload_cap_words, d_chunk_off, ctx->d_desc,
+                                    ctx->d_ctl, ctx->d_spill, ctx->d_ctl + 1, ctx->num_cu,
+                                    ctx->stream);
+        else
+            hf_launch_encode(d_data, n, lay, reinterpret_cast<const hf_cb_dev*>(d_codebook), d_side,
+                             d_payload, payload_cap_words, d_chunk_off, ctx->d_desc, ctx->d_ctl,
+                             ctx->d_spill, ctx->d_ctl + 1, ctx->num_cu, ctx->stream);
         toc(ctx);
         HF_HIP(hipGetLastError());
     }
@@ -449,6 +457,100 @@ int hf_encode(hf_ctx* ctx, const void* d_data, uint64_t n, int layout, const voi
         *h_total_words = ctx->h_ctl[8];
         return kerr_to_code(ctx->h_ctl[1]);
     }
+    return HF_OK;
+}
+
+int hf_encode(hf_ctx* ctx, const void* d_data, uint64_t n, int layout, const void* d_codebook,
+              uint8_t* d_side, uint32_t* d_payload, uint64_t payload_cap_words,
+              uint32_t* d_chunk_off, uint64_t* h_total_words) {
+    return encode_common(ctx, d_data, n, layout, d_codebook, false, d_side, d_payload,
+                         payload_cap_words, d_chunk_off, h_total_words);
+}
+
+/* ---- per-block codebooks --------------------------------------------------------------------------- */
+int hf_symbol_stat_chunks_dev(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
+                              uint32_t* d_freq_chunks) {
+    if (!ctx || !layout_ok(layout) || (n && (!d_data || !d_freq_chunks))) return HF_ERR_ARG;
+    if (!aligned16(d_data) || !aligned16(d_freq_chunks)) return HF_ERR_ALIGN;
+    if (n > (1ull << 40)) return HF_ERR_RANGE;
+    if (int rc = use_device(ctx)) return rc;
+    tic(ctx);
+    hf_launch_hist_chunks(d_data, n, norm_layout(layout), d_freq_chunks, ctx->stream);
+    toc(ctx);
+    HF_HIP(hipGetLastError());
+    return HF_OK;
+}
+
+int hf_system_codebook_chunks_dev(hf_ctx* ctx, const uint32_t* d_freq_chunks, uint64_t nchunks,
+                                  int mode, uint64_t min_freq_threshold, void* d_chunk_codebooks) {
+    if (!ctx || (nchunks && (!d_freq_chunks || !d_chunk_codebooks))) return HF_ERR_ARG;
+    if (mode != HF_MODE_BYPASS && mode != HF_MODE_HUFFMAN && mode != HF_MODE_AUTO) return HF_ERR_ARG;
+    if (!aligned16(d_freq_chunks) || !aligned16(d_chunk_codebooks)) return HF_ERR_ALIGN;
+    if (nchunks > 0x7FFFFFFFull) return HF_ERR_RANGE;
+    if (int rc = use_device(ctx)) return rc;
+    tic(ctx);
+    hf_launch_system_chunks(d_freq_chunks, nchunks, mode, min_freq_threshold,
+                            reinterpret_cast<hf_chunk_cb*>(d_chunk_codebooks), ctx->stream);
+    toc(ctx);
+    HF_HIP(hipGetLastError());
+    return HF_OK;
+}
+
+int hf_encode_chunks(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
+                     const void* d_chunk_codebooks, uint8_t* d_side, uint32_t* d_payload,
+                     uint64_t payload_cap_words, uint32_t* d_chunk_off, uint64_t* h_total_words) {
+    return encode_common(ctx, d_data, n, layout, d_chunk_codebooks, true, d_side, d_payload,
+                         payload_cap_words, d_chunk_off, h_total_words);
+}
+
+int hf_decode_chunks(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
+                     const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n, int layout,
+                     const void* d_chunk_codebooks, const uint32_t* d_chunk_ids, uint64_t n_ids,
+                     void* d_out, int check) {
+    if (!ctx || !layout_ok(layout)) return HF_ERR_ARG;
+    const uint64_t n_work = d_chunk_ids ? n_ids : hf_num_chunks(n);
+    if (n_work && (!d_payload || !d_chunk_off || !d_out || !d_chunk_codebooks)) return HF_ERR_ARG;
+    if (n_work && payload_words < 4) return HF_ERR_ARG;
+    const int lay = norm_layout(layout);
+    if (lay == HF_LAYOUT_BF16_EXP && n_work && !d_side) return HF_ERR_ARG;
+    if (!aligned16(d_payload) || !aligned16(d_side) || !aligned16(d_out) ||
+        !aligned16(d_chunk_off) || !aligned16(d_chunk_codebooks) || !aligned16(d_chunk_ids))
+        return HF_ERR_ALIGN;
+    if (n > (1ull << 40) || n_work > 0x7FFFFFFFull) return HF_ERR_RANGE;
+    if (int rc = use_device(ctx)) return rc;
+    HF_HIP(hipMemsetAsync(ctx->d_ctl, 0, 64, ctx->stream));
+    if (n_work) {
+        tic(ctx);
+        hf_launch_decode_chunks(d_payload, payload_words, d_chunk_off, d_side, n, lay,
+                                reinterpret_cast<const hf_chunk_cb*>(d_chunk_codebooks),
+                                d_chunk_ids, n_ids, d_out, ctx->d_ctl + 1, ctx->num_cu,
+                                ctx->stream);
+        toc(ctx);
+        HF_HIP(hipGetLastError());
+    }
+    if (check) {
+        HF_HIP(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl, 64, hipMemcpyDeviceToHost, ctx->stream));
+        HF_HIP(hipStreamSynchronize(ctx->stream));
+        return kerr_to_code(ctx->h_ctl[1]);
+    }
+    return HF_OK;
+}
+
+int hf_chunk_codebook_download(hf_ctx* ctx, const void* d_chunk_codebooks, uint64_t chunk,
+                               uint16_t* h_code, uint8_t* h_len, int* mode, uint32_t* entropy_q16) {
+    if (!ctx || !d_chunk_codebooks) return HF_ERR_ARG;
+    if (int rc = use_device(ctx)) return rc;
+    static_assert(sizeof(hf_chunk_cb) <= HF_CODEBOOK_DEV_BYTES, "staging buffer too small");
+    const hf_chunk_cb* src = reinterpret_cast<const hf_chunk_cb*>(d_chunk_codebooks) + chunk;
+    HF_HIP(hipMemcpyAsync(ctx->h_cb, src, sizeof(hf_chunk_cb), hipMemcpyDeviceToHost, ctx->stream));
+    HF_HIP(hipStreamSynchronize(ctx->stream));
+    const hf_chunk_cb* h = reinterpret_cast<const hf_chunk_cb*>(ctx->h_cb);
+    for (int s = 0; s < 256; ++s) {
+        if (h_code) h_code[s] = (uint16_t)(h->enc[s] & 0xFFFFu);
+        if (h_len) h_len[s] = (uint8_t)(h->enc[s] >> 16);
+    }
+    if (mode) *mode = (int)h->mode;
+    if (entropy_q16) *entropy_q16 = h->entropy_q16;
     return HF_OK;
 }
 

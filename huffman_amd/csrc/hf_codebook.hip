@@ -381,8 +381,7 @@ __global__ __launch_bounds__(64) void hf_k_system(const u64* __restrict__ freq25
             const u64 f = sorted[e];
             L.w[e] = f < thr ? 0ull : f;
         }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __syncthreads();
         stage_tree(L, N, lane);
         stage_adjust(L, N, HF_MAX_CODE_LEN, lane);
         stage_canonical(L, N, lane);
@@ -397,6 +396,55 @@ __global__ __launch_bounds__(64) void hf_k_system(const u64* __restrict__ freq25
         cb->mode = mode;
         cb->entropy_q16 = ent;
         cb->entropy_mode = emode;
+    }
+}
+
+// The same pipeline, one workgroup (one wavefront) per 16384-symbol chunk: per-block codebooks
+// for KV-cache pages.  Input uint32[256] counts per chunk; output one hf_chunk_cb record per
+// chunk: the encoder table by symbol plus the canonical order (rank2sym, length by rank) the
+// per-chunk decoder rebuilds its tables from.
+__global__ __launch_bounds__(64) void hf_k_system_chunks(const uint32_t* __restrict__ freq_chunks,
+                                                         const int mode_req, const u64 thr,
+                                                         hf_chunk_cb* __restrict__ cbs) {
+    __shared__ CbLds L;
+    __shared__ u64 sorted[256];
+    __shared__ u64 fq[256];
+    const int lane = hf_lane();
+    const int N = 256;
+    const uint32_t c = blockIdx.x;
+    for (int e = lane; e < N; e += 64) fq[e] = freq_chunks[(size_t)c * 256 + e];
+    __syncthreads();
+    stage_sort(fq, N, sorted, L.rank2sym, lane);
+    const uint32_t ent = stage_entropy(fq, N, lane);
+    const uint32_t emode = entropy_mode(ent);
+    const uint32_t mode = mode_req == HF_MODE_AUTO ? emode : (uint32_t)(mode_req & 1);
+    __syncthreads();
+    hf_chunk_cb* cb = cbs + c;
+    if (mode == HF_MODE_BYPASS) {
+        for (int s = lane; s < 256; s += 64) {
+            cb->enc[s] = (uint32_t)s | (8u << 16);
+            cb->rank2sym[s] = (uint8_t)s;
+            cb->len_by_rank[s] = 8;
+        }
+    } else {
+        for (int e = lane; e < N; e += 64) {
+            const u64 f = sorted[e];
+            L.w[e] = f < thr ? 0ull : f;
+        }
+        __syncthreads();
+        stage_tree(L, N, lane);
+        stage_adjust(L, N, HF_MAX_CODE_LEN, lane);
+        stage_canonical(L, N, lane);
+        for (int p = lane; p < N; p += 64) {
+            const int s = L.rank2sym[p];
+            cb->enc[s] = (uint32_t)L.code[p] | ((uint32_t)L.adj[p] << 16);
+            cb->rank2sym[p] = (uint8_t)s;
+            cb->len_by_rank[p] = (uint8_t)L.adj[p];
+        }
+    }
+    if (lane == 0) {
+        cb->mode = mode;
+        cb->entropy_q16 = ent;
     }
 }
 
@@ -508,6 +556,13 @@ void hf_launch_stage(hf_stage_io* io, int N, int op, int lmax, unsigned long lon
 void hf_launch_system(const unsigned long long* d_freq256, int mode, unsigned long long thr,
                       hf_cb_dev* cb, hipStream_t s) {
     hipLaunchKernelGGL(hf_k_system, dim3(1), dim3(64), 0, s, d_freq256, mode, thr, cb);
+}
+
+void hf_launch_system_chunks(const uint32_t* d_freq_chunks, uint64_t nchunks, int mode,
+                             unsigned long long thr, hf_chunk_cb* cbs, hipStream_t s) {
+    if (nchunks == 0) return;
+    hipLaunchKernelGGL(hf_k_system_chunks, dim3((unsigned)nchunks), dim3(64), 0, s, d_freq_chunks,
+                       mode, thr, cbs);
 }
 
 void hf_launch_tables(hf_cb_dev* cb, hipStream_t s) {

@@ -31,6 +31,19 @@ struct hf_cb_dev {
 };
 static_assert(sizeof(hf_cb_dev) <= HF_CODEBOOK_DEV_BYTES, "codebook struct outgrew its slot");
 
+// Per-chunk codebook record (HF_CHUNK_CODEBOOK_BYTES each): what the encoder needs by symbol
+// and what the decoder needs in canonical (rank) order.  Codes of one chunk are canonical in
+// rank order, so (rank2sym, len_by_rank) determines them completely.
+struct hf_chunk_cb {
+    uint32_t enc[256];        // code | len << 16, by raw symbol
+    uint8_t rank2sym[256];    // symbol of rank p, ranks ordered (count desc, symbol asc)
+    uint8_t len_by_rank[256]; // code length of rank p (non-decreasing in p)
+    uint32_t mode;
+    uint32_t entropy_q16;
+    uint32_t pad[2];
+};
+static_assert(sizeof(hf_chunk_cb) == HF_CHUNK_CODEBOOK_BYTES, "per-chunk codebook record size");
+
 // Global-memory I/O block of the single-wavefront table stages.
 struct hf_stage_io {
     uint64_t freq[256];
@@ -80,6 +93,20 @@ void hf_launch_encode(const void* d_data, uint64_t n, int layout, const hf_cb_de
                       uint32_t* d_chunk_off, unsigned long long* d_desc, uint32_t* d_ticket,
                       uint32_t* d_spill, uint32_t* d_err, int num_cu, hipStream_t s);
 size_t hf_encode_spill_bytes(int num_cu);
+void hf_launch_hist_chunks(const void* d_data, uint64_t n, int layout, uint32_t* d_freq_chunks,
+                           hipStream_t s);
+void hf_launch_system_chunks(const uint32_t* d_freq_chunks, uint64_t nchunks, int mode,
+                             unsigned long long thr, hf_chunk_cb* cbs, hipStream_t s);
+void hf_launch_encode_chunks(const void* d_data, uint64_t n, int layout, const hf_chunk_cb* cbs,
+                             uint8_t* d_side, uint32_t* d_payload, uint64_t cap_words,
+                             uint32_t* d_chunk_off, unsigned long long* d_desc,
+                             uint32_t* d_ticket, uint32_t* d_spill, uint32_t* d_err, int num_cu,
+                             hipStream_t s);
+void hf_launch_decode_chunks(const uint32_t* d_payload, uint64_t payload_words,
+                             const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n,
+                             int layout, const hf_chunk_cb* cbs, const uint32_t* d_chunk_ids,
+                             uint64_t n_ids, void* d_out, uint32_t* d_err, int num_cu,
+                             hipStream_t s);
 void hf_launch_decode(const uint32_t* d_payload, uint64_t payload_words,
                       const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n, int layout,
                       const hf_cb_dev* cb, void* d_out, uint32_t* d_err, int num_cu,

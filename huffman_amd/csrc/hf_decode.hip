@@ -21,22 +21,52 @@ typedef unsigned long long u64;
 constexpr int kWaves = 8;
 constexpr int kStageWords = 1792;  // payload window per wavefront (7 KiB)
 
+// Tables of a stream-wide codebook (any prefix-free code): shared by the workgroup.
 struct DecTables {
     uint16_t lut[HF_LUT_SIZE];  // first level, by the next 12 bits
     uint16_t sub[256 * 16];     // second level, 16 entries per escape, by the following 4 bits
+
+    // a code longer than 12 bits: the first-level entry names a 16-entry table for bits 13..16
+    __device__ __forceinline__ uint32_t long_code(const uint32_t top, const uint32_t esc,
+                                                  uint32_t& len) const {
+        const uint32_t e2 = sub[(esc << 4) | ((top >> (32 - HF_LUT_BITS - 4)) & 0xFu)];
+        len = e2 & 0xFFu;
+        return e2 >> 8;
+    }
 };
 
-__device__ __forceinline__ uint32_t decode_one(u64& win, int& nb, const DecTables& T,
-                                               uint32_t* err) {
+// Tables of one chunk's codebook, rebuilt by the decoding wavefront from the canonical order:
+// a private first-level table plus, for the codes of 13..16 bits, the start/end of each
+// length's block in the left-aligned 16-bit code space and the rank of its first code.
+struct ChunkTables {
+    const uint16_t* lut;     // LDS, HF_LUT_SIZE entries of this wavefront
+    const uint8_t* rank2sym; // LDS, 256 entries
+    uint32_t start[4], end[4], off[4];  // lengths 13, 14, 15, 16 (wave-uniform)
+
+    __device__ __forceinline__ uint32_t long_code(const uint32_t top, const uint32_t,
+                                                  uint32_t& len) const {
+        const uint32_t v16 = top >> 16;
+        uint32_t p = 0;
+        len = 0;
+#pragma unroll
+        for (int k = 3; k >= 0; --k) {  // the lowest matching block wins
+            if (v16 < end[k]) {
+                len = 13u + k;
+                p = off[k] + ((v16 - start[k]) >> (3 - k));
+            }
+        }
+        return rank2sym[p & 255u];
+    }
+};
+
+template <class TAB>
+__device__ __forceinline__ uint32_t decode_one(u64& win, int& nb, const TAB& T, uint32_t* err) {
     const uint32_t top = (uint32_t)(win >> 32);
     const uint32_t e = T.lut[top >> (32 - HF_LUT_BITS)];
     uint32_t len = e & 0xFFu;
     uint32_t sym = e >> 8;
     if (__builtin_expect(len == 0, 0)) {
-        // a code longer than 12 bits: the entry names a 16-entry table for bits 13..16
-        const uint32_t e2 = T.sub[(sym << 4) | ((top >> (32 - HF_LUT_BITS - 4)) & 0xFu)];
-        len = e2 & 0xFFu;
-        sym = e2 >> 8;
+        sym = T.long_code(top, sym, len);
         if (len == 0) {  // no code matches: flag it and keep moving
             atomicOr(err, HF_KERR_CORRUPT);
             len = 1;
@@ -84,11 +114,11 @@ __device__ __forceinline__ void refill(const bool need, u64& win, int& nb, uint3
 }
 
 // A full chunk (16384 symbols).  Returns the global index of the first unread payload word.
-template <int LAYOUT>
+template <int LAYOUT, class TAB>
 __device__ u64 decode_chunk_full(const uint32_t* __restrict__ payload, const u64 payload_words,
                                  const u64 off0, const u64 off1,
                                  const uint8_t* __restrict__ side_chunk,
-                                 void* __restrict__ out_chunk, const DecTables& T,
+                                 void* __restrict__ out_chunk, const TAB& T,
                                  uint32_t* __restrict__ stg, uint32_t* err, const int lane) {
     u64 gs = off0 & ~3ull;
     stage_window(payload, payload_words, gs, stg, lane);
@@ -146,12 +176,12 @@ __device__ u64 decode_chunk_full(const uint32_t* __restrict__ payload, const u64
 }
 
 // The last, partial chunk: same schedule with per-symbol validity; speed does not matter.
-template <int LAYOUT>
+template <int LAYOUT, class TAB>
 __device__ u64 decode_chunk_tail(const uint32_t* __restrict__ payload, const u64 payload_words,
                                  const u64 off0, const u64 off1,
                                  const uint8_t* __restrict__ side_chunk,
                                  void* __restrict__ out_chunk, const uint32_t nvalid,
-                                 const DecTables& T, uint32_t* __restrict__ stg, uint32_t* err,
+                                 const TAB& T, uint32_t* __restrict__ stg, uint32_t* err,
                                  const int lane) {
     u64 gs = off0 & ~3ull;
     stage_window(payload, payload_words, gs, stg, lane);
@@ -241,7 +271,165 @@ __global__ __launch_bounds__(kWaves * 64) void hf_k_decode(
     }
 }
 
+// ---- per-chunk codebooks -------------------------------------------------------------------
+constexpr int kWavesC = 4;
+
+// Rebuild one chunk's decode tables from its canonical order.  Lane l holds ranks 4l .. 4l+3.
+// The codes of ranks 0, 1, 2, ... tile the left-aligned 16-bit code space front to back, rank p
+// covering 2^(16 - len_p) values, so a prefix sum of those widths gives every code.
+__device__ void build_chunk_tables(const hf_chunk_cb* __restrict__ ccb, uint16_t* __restrict__ lut,
+                                   uint8_t* __restrict__ r2s, uint32_t* __restrict__ tmp,
+                                   ChunkTables& T, const int lane) {
+    const uint32_t lens4 = reinterpret_cast<const uint32_t*>(ccb->len_by_rank)[lane];
+    const uint32_t syms4 = reinterpret_cast<const uint32_t*>(ccb->rank2sym)[lane];
+    reinterpret_cast<uint32_t*>(r2s)[lane] = syms4;
+    // zero the first level: entries no short code covers stay "escape"
+#pragma unroll
+    for (int k = 0; k < HF_LUT_SIZE * 2 / 16 / 64; ++k)
+        reinterpret_cast<uint4*>(lut)[k * 64 + lane] = make_uint4(0, 0, 0, 0);
+    uint32_t len[4], width[4], start[4];
+    uint32_t lane_total = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        len[i] = (lens4 >> (8 * i)) & 0xFFu;
+        width[i] = (len[i] >= 1 && len[i] <= 16) ? (1u << (16 - len[i])) : 0u;
+        start[i] = lane_total;
+        lane_total += width[i];
+    }
+    uint32_t incl = lane_total;  // inclusive scan over lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    const uint32_t lane_base = incl - lane_total;
+    // counts per length -> blocks of the 13..16-bit codes
+    uint32_t cnt_below = 0, start_acc = 0;
+    for (uint32_t d = 1; d <= 16; ++d) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c += (uint32_t)__popcll(__ballot(len[i] == d));
+        if (d >= 13) {
+            T.start[d - 13] = start_acc;
+            T.off[d - 13] = cnt_below;
+            T.end[d - 13] = start_acc + (c << (16 - d));
+        }
+        cnt_below += c;
+        start_acc += c << (16 - d);
+    }
+    // per-rank fill descriptor for the cooperative phase: first entry | len << 12 | sym << 24
+    uint32_t n_wide = 0;  // ranks with span >= 64 (len <= 6); they are the first ranks
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t s16 = lane_base + start[i];
+        const uint32_t sym = (syms4 >> (8 * i)) & 0xFFu;
+        tmp[lane * 4 + i] = ((s16 >> 4) & 0xFFFu) | (len[i] << 12) | (sym << 24);
+        n_wide += (uint32_t)__popcll(__ballot(len[i] >= 1 && len[i] <= 6));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // wide codes: the whole wavefront fills one code's span, 64 entries per step
+    for (uint32_t q = 0; q < n_wide; ++q) {
+        const uint32_t d = tmp[q];
+        const uint32_t first = d & 0xFFFu, L = (d >> 12) & 0x1Fu;
+        const uint16_t val = (uint16_t)(((d >> 24) << 8) | L);
+        const uint32_t span = 1u << (HF_LUT_BITS - L);
+        for (uint32_t k = lane; k < span; k += 64) lut[first + k] = val;
+    }
+    // narrow codes (7..12 bits, at most 32 entries each): every lane fills its own ranks
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (len[i] >= 7 && len[i] <= HF_LUT_BITS) {
+            const uint32_t first = ((lane_base + start[i]) >> 4) & 0xFFFu;
+            const uint16_t val = (uint16_t)((((syms4 >> (8 * i)) & 0xFFu) << 8) | len[i]);
+            const uint32_t span = 1u << (HF_LUT_BITS - len[i]);
+            for (uint32_t k = 0; k < span; ++k) lut[first + k] = val;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    T.lut = lut;
+    T.rank2sym = r2s;
+}
+
+template <int LAYOUT>
+__global__ __launch_bounds__(kWavesC * 64) void hf_k_decode_chunks(
+    const uint32_t* __restrict__ payload, const uint64_t payload_words,
+    const uint32_t* __restrict__ chunk_off, const uint8_t* __restrict__ side, const uint64_t n,
+    const uint32_t nchunks, const hf_chunk_cb* __restrict__ cbs,
+    const uint32_t* __restrict__ chunk_ids, const uint32_t n_work, void* __restrict__ out,
+    uint32_t* err) {
+    __shared__ __attribute__((aligned(16))) uint16_t lut_all[kWavesC][HF_LUT_SIZE];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[kWavesC][kStageWords];
+    __shared__ __attribute__((aligned(16))) uint32_t tmp_all[kWavesC][256];
+    __shared__ __attribute__((aligned(16))) uint8_t r2s_all[kWavesC][256];
+    const int lane = hf_lane();
+    const int wv = threadIdx.x >> 6;
+    const uint32_t wave = blockIdx.x * kWavesC + wv;
+    const uint32_t nwaves = gridDim.x * kWavesC;
+    const size_t elem_bytes = LAYOUT == HF_LAYOUT_BF16_EXP ? 2 : 1;
+    for (uint32_t k = wave; k < n_work; k += nwaves) {
+        // decode-on-read: work item k is chunk chunk_ids[k], written to slot k of `out`
+        const uint32_t c = chunk_ids ? __builtin_amdgcn_readfirstlane(chunk_ids[k]) : k;
+        if (c >= nchunks) {
+            if (lane == 0) atomicOr(err, HF_KERR_CORRUPT);
+            continue;
+        }
+        const uint32_t off0 = __builtin_amdgcn_readfirstlane(chunk_off[c]);
+        const uint32_t off1 = __builtin_amdgcn_readfirstlane(chunk_off[c + 1]);
+        const uint64_t first = (uint64_t)c * HF_CHUNK_SYMS;
+        const uint64_t left = n - first;
+        const uint32_t nvalid = left < HF_CHUNK_SYMS ? (uint32_t)left : HF_CHUNK_SYMS;
+        const bool sane = off1 >= off0 && (uint64_t)off1 <= payload_words &&
+                          (chunk_ids == nullptr || nvalid == HF_CHUNK_SYMS);
+        if (!sane) {
+            if (lane == 0) atomicOr(err, HF_KERR_CORRUPT);
+            continue;
+        }
+        ChunkTables T;
+        build_chunk_tables(cbs + c, lut_all[wv], r2s_all[wv], tmp_all[wv], T, lane);
+        const uint8_t* side_chunk = side ? side + first : nullptr;
+        const uint64_t out_first = chunk_ids ? (uint64_t)k * HF_CHUNK_SYMS : first;
+        void* out_chunk = reinterpret_cast<uint8_t*>(out) + out_first * elem_bytes;
+        u64 end;
+        if (nvalid == HF_CHUNK_SYMS)
+            end = decode_chunk_full<LAYOUT>(payload, payload_words, off0, off1, side_chunk,
+                                            out_chunk, T, stage[wv], err, lane);
+        else
+            end = decode_chunk_tail<LAYOUT>(payload, payload_words, off0, off1, side_chunk,
+                                            out_chunk, nvalid, T, stage[wv], err, lane);
+        if (end != off1 && lane == 0) atomicOr(err, HF_KERR_CORRUPT);
+        // the tables are rebuilt for the next chunk: all reads of this one are done
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace
+
+void hf_launch_decode_chunks(const uint32_t* d_payload, uint64_t payload_words,
+                             const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n,
+                             int layout, const hf_chunk_cb* cbs, const uint32_t* d_chunk_ids,
+                             uint64_t n_ids, void* d_out, uint32_t* d_err, int num_cu,
+                             hipStream_t s) {
+    const uint64_t nchunks = (n + HF_CHUNK_SYMS - 1) / HF_CHUNK_SYMS;
+    const uint64_t n_work = d_chunk_ids ? n_ids : nchunks;
+    if (n_work == 0) return;
+    uint64_t grid = (n_work + kWavesC - 1) / kWavesC;
+    const uint64_t cap = (uint64_t)num_cu * 2;  // two 66 KiB workgroups fit one CU's LDS
+    if (grid > cap) grid = cap;
+    if (layout == HF_LAYOUT_BF16_EXP)
+        hipLaunchKernelGGL(hf_k_decode_chunks<HF_LAYOUT_BF16_EXP>, dim3((unsigned)grid),
+                           dim3(kWavesC * 64), 0, s, d_payload, payload_words, d_chunk_off, d_side,
+                           n, (uint32_t)nchunks, cbs, d_chunk_ids, (uint32_t)n_work, d_out, d_err);
+    else
+        hipLaunchKernelGGL(hf_k_decode_chunks<HF_LAYOUT_U8>, dim3((unsigned)grid),
+                           dim3(kWavesC * 64), 0, s, d_payload, payload_words, d_chunk_off,
+                           (const uint8_t*)nullptr, n, (uint32_t)nchunks, cbs, d_chunk_ids,
+                           (uint32_t)n_work, d_out, d_err);
+}
 
 void hf_launch_decode(const uint32_t* d_payload, uint64_t payload_words,
                       const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n, int layout,

@@ -263,18 +263,23 @@ __device__ uint32_t encode_chunk(const void* chunk_in, const uint32_t nvalid,
     return st.pos;
 }
 
-template <int LAYOUT>
+// PER_CHUNK = false: one codebook (hf_cb_dev) for the whole stream, its encoder table shared
+// by the workgroup.  PER_CHUNK = true: chunk c is coded with record c of an hf_chunk_cb array
+// (per-block codebooks); each wavefront keeps its chunk's table in its own 1 KiB of LDS.
+template <int LAYOUT, bool PER_CHUNK>
 __global__ __launch_bounds__(kWaves * 64) void hf_k_encode(
     const void* __restrict__ data, const uint64_t n, const uint32_t nchunks,
-    const hf_cb_dev* __restrict__ cb, uint8_t* __restrict__ side, uint32_t* __restrict__ payload,
+    const void* __restrict__ cbv, uint8_t* __restrict__ side, uint32_t* __restrict__ payload,
     const uint64_t cap_words, uint32_t* __restrict__ chunk_off, u64* desc, uint32_t* ticket,
     uint32_t* spill_base, uint32_t* err) {
-    __shared__ uint32_t enc[256];
+    __shared__ uint32_t enc_all[PER_CHUNK ? kWaves * 256 : 256];
     __shared__ uint32_t stg_all[kWaves][kStgWords];
     __shared__ uint32_t tile_ticket;
     __shared__ uint32_t tile_tot[kWaves];
     __shared__ u64 tile_base;
-    enc[threadIdx.x] = cb->enc[threadIdx.x];
+    if (!PER_CHUNK)
+        enc_all[threadIdx.x] = reinterpret_cast<const hf_cb_dev*>(cbv)->enc[threadIdx.x];
+    uint32_t* enc = PER_CHUNK ? enc_all + (threadIdx.x >> 6) * 256 : enc_all;
 
     const int lane = hf_lane();
     const int wave = threadIdx.x >> 6;
@@ -301,6 +306,14 @@ __global__ __launch_bounds__(kWaves * 64) void hf_k_encode(
             const uint32_t nvalid = left < HF_CHUNK_SYMS ? (uint32_t)left : HF_CHUNK_SYMS;
             const void* chunk_in = reinterpret_cast<const uint8_t*>(data) + first * elem_bytes;
             uint8_t* side_chunk = side ? side + first : nullptr;
+            if (PER_CHUNK) {
+                const hf_chunk_cb* ccb = reinterpret_cast<const hf_chunk_cb*>(cbv) + c;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) enc[lane + 64 * k] = ccb->enc[lane + 64 * k];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
             if (nvalid == HF_CHUNK_SYMS)
                 total = encode_chunk<LAYOUT, true>(chunk_in, nvalid, enc, stg, spill, side_chunk,
                                                    lane);
@@ -374,21 +387,41 @@ size_t hf_encode_spill_bytes(int num_cu) {
     return (size_t)num_cu * 2 * kWaves * kSpillWords * sizeof(uint32_t);
 }
 
+template <bool PER_CHUNK>
+static void launch_encode_impl(const void* d_data, uint64_t n, int layout, const void* cb,
+                               uint8_t* d_side, uint32_t* d_payload, uint64_t cap_words,
+                               uint32_t* d_chunk_off, unsigned long long* d_desc,
+                               uint32_t* d_ticket, uint32_t* d_spill, uint32_t* d_err, int num_cu,
+                               hipStream_t s) {
+    const uint64_t nchunks = (n + HF_CHUNK_SYMS - 1) / HF_CHUNK_SYMS;
+    if (nchunks == 0) return;
+    uint64_t grid = (nchunks + kWaves - 1) / kWaves;
+    const uint64_t cap = (uint64_t)num_cu * 2;  // two ~70 KiB workgroups fit one CU's LDS
+    if (grid > cap) grid = cap;
+    if (layout == HF_LAYOUT_BF16_EXP)
+        hipLaunchKernelGGL((hf_k_encode<HF_LAYOUT_BF16_EXP, PER_CHUNK>), dim3((unsigned)grid),
+                           dim3(kWaves * 64), 0, s, d_data, n, (uint32_t)nchunks, cb, d_side,
+                           d_payload, cap_words, d_chunk_off, d_desc, d_ticket, d_spill, d_err);
+    else
+        hipLaunchKernelGGL((hf_k_encode<HF_LAYOUT_U8, PER_CHUNK>), dim3((unsigned)grid),
+                           dim3(kWaves * 64), 0, s, d_data, n, (uint32_t)nchunks, cb,
+                           (uint8_t*)nullptr, d_payload, cap_words, d_chunk_off, d_desc, d_ticket,
+                           d_spill, d_err);
+}
+
 void hf_launch_encode(const void* d_data, uint64_t n, int layout, const hf_cb_dev* cb,
                       uint8_t* d_side, uint32_t* d_payload, uint64_t cap_words,
                       uint32_t* d_chunk_off, unsigned long long* d_desc, uint32_t* d_ticket,
                       uint32_t* d_spill, uint32_t* d_err, int num_cu, hipStream_t s) {
-    const uint64_t nchunks = (n + HF_CHUNK_SYMS - 1) / HF_CHUNK_SYMS;
-    if (nchunks == 0) return;
-    uint64_t grid = (nchunks + kWaves - 1) / kWaves;
-    const uint64_t cap = (uint64_t)num_cu * 2;  // two 67 KiB workgroups fit one CU's LDS
-    if (grid > cap) grid = cap;
-    if (layout == HF_LAYOUT_BF16_EXP)
-        hipLaunchKernelGGL(hf_k_encode<HF_LAYOUT_BF16_EXP>, dim3((unsigned)grid),
-                           dim3(kWaves * 64), 0, s, d_data, n, (uint32_t)nchunks, cb, d_side,
-                           d_payload, cap_words, d_chunk_off, d_desc, d_ticket, d_spill, d_err);
-    else
-        hipLaunchKernelGGL(hf_k_encode<HF_LAYOUT_U8>, dim3((unsigned)grid), dim3(kWaves * 64), 0, s,
-                           d_data, n, (uint32_t)nchunks, cb, (uint8_t*)nullptr, d_payload,
-                           cap_words, d_chunk_off, d_desc, d_ticket, d_spill, d_err);
+    launch_encode_impl<false>(d_data, n, layout, cb, d_side, d_payload, cap_words, d_chunk_off,
+                              d_desc, d_ticket, d_spill, d_err, num_cu, s);
+}
+
+void hf_launch_encode_chunks(const void* d_data, uint64_t n, int layout, const hf_chunk_cb* cbs,
+                             uint8_t* d_side, uint32_t* d_payload, uint64_t cap_words,
+                             uint32_t* d_chunk_off, unsigned long long* d_desc,
+                             uint32_t* d_ticket, uint32_t* d_spill, uint32_t* d_err, int num_cu,
+                             hipStream_t s) {
+    launch_encode_impl<true>(d_data, n, layout, cbs, d_side, d_payload, cap_words, d_chunk_off,
+                             d_desc, d_ticket, d_spill, d_err, num_cu, s);
 }

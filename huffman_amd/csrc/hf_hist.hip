@@ -79,7 +79,85 @@ __global__ __launch_bounds__(kThreads) void hf_k_hist(const uint4* __restrict__ 
     if (sum) atomicAdd(&freq[tid], (unsigned long long)sum);
 }
 
+// One histogram per 16384-symbol chunk (a KV-cache page): one wavefront per chunk, 8 copies of
+// the 256 counters in LDS (lane l adds into copy l mod 8), folded and written as uint32[256].
+constexpr int kChunkCopies = 8;
+constexpr int kChunkWaves = 4;
+
+template <int LAYOUT>
+__global__ __launch_bounds__(kChunkWaves * 64) void hf_k_hist_chunks(
+    const void* __restrict__ data, const uint64_t n, const uint32_t nchunks,
+    uint32_t* __restrict__ freq_chunks) {
+    __shared__ uint32_t h_all[kChunkWaves][256 * kChunkCopies];
+    const int lane = hf_lane();
+    const int wv = threadIdx.x >> 6;
+    uint32_t* h = h_all[wv];
+    const uint32_t c = blockIdx.x * kChunkWaves + wv;
+    if (c >= nchunks) return;
+    for (int i = lane; i < 256 * kChunkCopies; i += 64) h[i] = 0;
+    const uint64_t first = (uint64_t)c * HF_CHUNK_SYMS;
+    const uint64_t left = n - first;
+    const uint32_t nvalid = left < HF_CHUNK_SYMS ? (uint32_t)left : HF_CHUNK_SYMS;
+    const uint32_t copy = lane & (kChunkCopies - 1);
+    if (LAYOUT == HF_LAYOUT_BF16_EXP) {
+        const uint16_t* p16 = reinterpret_cast<const uint16_t*>(data) + first;
+        const uint32_t nvec = nvalid / 8;
+        for (uint32_t v = lane; v < nvec; v += 64) {
+            const uint4 x = reinterpret_cast<const uint4*>(p16)[v];
+            const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                atomicAdd(&h[((w[i] >> 7) & 0xFFu) * kChunkCopies + copy], 1u);
+                atomicAdd(&h[((w[i] >> 23) & 0xFFu) * kChunkCopies + copy], 1u);
+            }
+        }
+        for (uint32_t i = nvec * 8 + lane; i < nvalid; i += 64)
+            atomicAdd(&h[((p16[i] >> 7) & 0xFFu) * kChunkCopies + copy], 1u);
+    } else {
+        const uint8_t* p8 = reinterpret_cast<const uint8_t*>(data) + first;
+        const uint32_t nvec = nvalid / 16;
+        for (uint32_t v = lane; v < nvec; v += 64) {
+            const uint4 x = reinterpret_cast<const uint4*>(p8)[v];
+            const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                atomicAdd(&h[(w[i] & 0xFFu) * kChunkCopies + copy], 1u);
+                atomicAdd(&h[((w[i] >> 8) & 0xFFu) * kChunkCopies + copy], 1u);
+                atomicAdd(&h[((w[i] >> 16) & 0xFFu) * kChunkCopies + copy], 1u);
+                atomicAdd(&h[(w[i] >> 24) * kChunkCopies + copy], 1u);
+            }
+        }
+        for (uint32_t i = nvec * 16 + lane; i < nvalid; i += 64)
+            atomicAdd(&h[p8[i] * kChunkCopies + copy], 1u);
+    }
+    // the wavefront's own LDS operations complete in order; no other wavefront touches h
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int s = lane + 64 * k;
+        uint32_t sum = 0;
+#pragma unroll
+        for (int i = 0; i < kChunkCopies; ++i) sum += h[s * kChunkCopies + ((i + lane) & (kChunkCopies - 1))];
+        freq_chunks[(size_t)c * 256 + s] = sum;
+    }
+}
+
 }  // namespace
+
+void hf_launch_hist_chunks(const void* d_data, uint64_t n, int layout, uint32_t* d_freq_chunks,
+                           hipStream_t s) {
+    const uint64_t nchunks = (n + HF_CHUNK_SYMS - 1) / HF_CHUNK_SYMS;
+    if (nchunks == 0) return;
+    const unsigned grid = (unsigned)((nchunks + kChunkWaves - 1) / kChunkWaves);
+    if (layout == HF_LAYOUT_BF16_EXP)
+        hipLaunchKernelGGL(hf_k_hist_chunks<HF_LAYOUT_BF16_EXP>, dim3(grid), dim3(kChunkWaves * 64),
+                           0, s, d_data, n, (uint32_t)nchunks, d_freq_chunks);
+    else
+        hipLaunchKernelGGL(hf_k_hist_chunks<HF_LAYOUT_U8>, dim3(grid), dim3(kChunkWaves * 64), 0, s,
+                           d_data, n, (uint32_t)nchunks, d_freq_chunks);
+}
 
 void hf_launch_hist(const void* d_data, uint64_t n, int layout, unsigned long long* d_freq256,
                     int num_cu, hipStream_t s) {

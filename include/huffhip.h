@@ -176,6 +176,33 @@ int hf_decode(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
               const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n, int layout,
               const void* d_codebook, void* d_out, int check);
 
+/* ---- per-block codebooks (one EntropyAwareTreeBuilder run per 16384-symbol chunk) ---------- *
+ * The reference builds one codebook per block it is fed (symbol_stat.scala:26-33 clears the
+ * counters on every `start`); for KV-cache pages a block is one chunk.  All four calls are
+ * device to device and only enqueue work unless stated.                                       */
+#define HF_CHUNK_CODEBOOK_BYTES 1552u /* one record per chunk, opaque */
+/* SymbolStat per chunk: d_freq_chunks = uint32[nchunks][256], overwritten. */
+int hf_symbol_stat_chunks_dev(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
+                              uint32_t* d_freq_chunks);
+/* sort -> entropy decision -> tree -> adjust -> canonical codes -> rank->symbol scatter, once
+ * per chunk; d_chunk_codebooks = nchunks records of HF_CHUNK_CODEBOOK_BYTES. */
+int hf_system_codebook_chunks_dev(hf_ctx* ctx, const uint32_t* d_freq_chunks, uint64_t nchunks,
+                                  int mode, uint64_t min_freq_threshold, void* d_chunk_codebooks);
+/* as hf_encode, chunk c coded with record c */
+int hf_encode_chunks(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
+                     const void* d_chunk_codebooks, uint8_t* d_side, uint32_t* d_payload,
+                     uint64_t payload_cap_words, uint32_t* d_chunk_off, uint64_t* h_total_words);
+/* as hf_decode.  d_chunk_ids == NULL: every chunk to its own place in d_out (n elements).
+ * Otherwise decode-on-read: the n_ids listed chunks, in that order, to d_out + k * 16384
+ * elements (all listed chunks must be full chunks; `n` still describes the encoded stream). */
+int hf_decode_chunks(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
+                     const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n, int layout,
+                     const void* d_chunk_codebooks, const uint32_t* d_chunk_ids, uint64_t n_ids,
+                     void* d_out, int check);
+/* bulk read of one record: code/length by symbol, mode, entropy (synchronises) */
+int hf_chunk_codebook_download(hf_ctx* ctx, const void* d_chunk_codebooks, uint64_t chunk,
+                               uint16_t* h_code, uint8_t* h_len, int* mode, uint32_t* entropy_q16);
+
 /* ---- TreeQualityAnalyzer (tree_q_analyser.scala:10-47) ------------------------------------- */
 int hf_quality(hf_ctx* ctx, const uint64_t* h_freq, const uint8_t* h_len, int N, int wt_width,
                uint16_t* avg_len_q8, uint16_t* efficiency, uint16_t* compression_ratio);

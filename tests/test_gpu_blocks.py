@@ -1,0 +1,123 @@
+"""GPU parity of the per-block path: one codebook per 16384-symbol chunk (fp8 KV-cache pages
+with per-block EntropyAwareTreeBuilder codebooks, decode-on-read), checked against the CPU
+oracle run block by block."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import gaussian_bf16, skewed_symbols
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+CH = 16384
+
+
+def kv_pages_fp8(n_pages: int, seed: int = 7) -> np.ndarray:
+    """16-token x 1024-byte pages: N(0,1) x per-channel scale -> fp8 E4M3 bytes."""
+    g = torch.Generator().manual_seed(seed)
+    scale = torch.exp(torch.randn(1024, generator=g) * 0.7)
+    x = torch.randn(n_pages * 16, 1024, generator=g) * scale
+    return x.to(torch.float8_e4m3fn).view(torch.uint8).reshape(-1).numpy()
+
+
+def oracle_blocks(orc, sym, mode):
+    """Block-by-block oracle: per-chunk codebook, payload concatenated, offsets accumulated."""
+    payloads, offs, books, total = [], [0], [], 0
+    for lo in range(0, sym.size, CH):
+        blk = sym[lo:lo + CH]
+        f = orc.aw_symbol_stat(blk, 256, 32)
+        ent = orc.rp_entropy_q16_u64(f)
+        m = orc.aw_adaptive_mode(ent) if mode == 2 else mode
+        if m == 1:
+            code, lens = orc.rp_system_codebook(f, 64, 0, 16)
+        else:
+            code, lens = np.arange(256, dtype=np.uint16), np.full(256, 8, np.uint8)
+        p, _ = orc.rp_encode(blk, code, lens)
+        payloads.append(p)
+        total += p.size
+        offs.append(total)
+        books.append((code, lens, m, ent))
+    payload = np.concatenate(payloads) if payloads else np.zeros(0, np.uint32)
+    return payload, np.array(offs, np.uint32), books
+
+
+@pytest.mark.parametrize("n_pages,mode", [(1, 1), (5, 1), (33, 2), (8, 0)])
+def test_fp8_pages_vs_oracle(hf, orc, n_pages, mode):
+    sym = kv_pages_fp8(n_pages, seed=7 + n_pages)
+    t = torch.from_numpy(sym).to(DEV)
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    s = sys_.encode_blocks(t, mode=mode)
+    payload, off, books = oracle_blocks(orc, sym, mode)
+    # per-block histograms and codebooks
+    freq = s.chunk_freq.cpu().numpy().view(np.uint32).reshape(-1, 256)
+    for c in range(n_pages):
+        assert np.array_equal(freq[c], orc.aw_symbol_stat(sym[c * CH:(c + 1) * CH], 256, 32))
+        code, lens, m, ent = sys_.block_codebook(s, c)
+        assert (m, ent) == (books[c][2], books[c][3])
+        assert np.array_equal(code, books[c][0]) and np.array_equal(lens, books[c][1])
+    assert s.total_words == payload.size
+    assert np.array_equal(s.chunk_off[: n_pages + 1].cpu().numpy().view(np.uint32), off)
+    assert np.array_equal(s.payload[: payload.size].cpu().numpy().view(np.uint32), payload)
+    out = hf.ParrallelHuffmanDecoder().decode(s)
+    assert torch.equal(out, t)
+
+
+def test_decode_on_read_random_page_order(hf):
+    n_pages = 64
+    sym = kv_pages_fp8(n_pages, seed=3)
+    t = torch.from_numpy(sym).to(DEV)
+    s = hf.EntropyAwareHuffmanSystem().encode_blocks(t, mode=hf.HF_MODE_HUFFMAN)
+    ids = torch.from_numpy(np.random.default_rng(0).permutation(n_pages)[:40].astype(np.int32)).to(DEV)
+    out = hf.ParrallelHuffmanDecoder().decode_blocks(s, chunk_ids=ids)
+    exp = t.view(n_pages, CH)[ids.long()].reshape(-1)
+    assert torch.equal(out, exp)
+    # an id past the stream is reported
+    bad = torch.tensor([1, 10_000], dtype=torch.int32, device=DEV)
+    with pytest.raises(hf.HuffhipError) as ei:
+        hf.ParrallelHuffmanDecoder().decode_blocks(s, chunk_ids=bad)
+    assert ei.value.code == -7
+
+
+@pytest.mark.parametrize("kind", ["one", "two", "fib", "geometric", "uniform"])
+def test_degenerate_blocks(hf, orc, kind):
+    # 1-2 symbol blocks, blocks that need the length limiter, ragged tail
+    sym = skewed_symbols(3 * CH + 1234, 11, kind)
+    t = torch.from_numpy(sym).to(DEV)
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    s = sys_.encode_blocks(t, mode=hf.HF_MODE_HUFFMAN)
+    payload, off, books = oracle_blocks(orc, sym, 1)
+    assert s.total_words == payload.size
+    assert np.array_equal(s.payload[: payload.size].cpu().numpy().view(np.uint32), payload)
+    for c in range(4):
+        code, lens, _, _ = sys_.block_codebook(s, c)
+        assert np.array_equal(code, books[c][0]) and np.array_equal(lens, books[c][1])
+        assert lens.max() <= 16
+    assert torch.equal(hf.ParrallelHuffmanDecoder().decode(s), t)
+
+
+def test_bf16_blocks(hf, orc):
+    w = gaussian_bf16(5 * CH + 77, seed=4)
+    t = torch.from_numpy(w.view(np.int16)).to(DEV).view(torch.bfloat16)
+    s = hf.EntropyAwareHuffmanSystem().encode_blocks(t, mode=hf.HF_MODE_HUFFMAN)
+    sym, side = orc.symbolize(w, orc.LAYOUT_BF16_EXP)
+    payload, off, _ = oracle_blocks(orc, sym, 1)
+    assert s.total_words == payload.size
+    assert np.array_equal(s.payload[: payload.size].cpu().numpy().view(np.uint32), payload)
+    assert np.array_equal(s.side[: w.size].cpu().numpy(), side)
+    out = hf.ParrallelHuffmanDecoder().decode(s)
+    assert torch.equal(out.view(torch.int16), t.view(torch.int16))
+
+
+def test_many_pages_round_trip(hf):
+    # 2048 pages (32 MiB): round trip plus the size identity sum(freq * len) <= payload bits
+    n_pages = 2048
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(n_pages * CH, generator=g, device=DEV)
+    t = x.to(torch.float8_e4m3fn).view(torch.uint8)
+    s = hf.EntropyAwareHuffmanSystem().encode_blocks(t, mode=hf.HF_MODE_HUFFMAN)
+    out = hf.ParrallelHuffmanDecoder().decode(s)
+    assert torch.equal(out, t)
+    ids = torch.randperm(n_pages, device=DEV)[:512].to(torch.int32)
+    part = hf.ParrallelHuffmanDecoder().decode_blocks(s, chunk_ids=ids)
+    assert torch.equal(part, t.view(n_pages, CH)[ids.long()].reshape(-1))
+    assert 1.0 < s.ratio() < 2.0
