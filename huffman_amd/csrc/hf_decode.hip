@@ -20,6 +20,7 @@ namespace {
 typedef unsigned long long u64;
 constexpr int kWaves = 8;
 constexpr int kStageWords = 1792;  // payload window per wavefront (7 KiB)
+constexpr int kStageSlack = 64;    // never staged: room for the reads of a clamped position
 
 // Tables of a stream-wide codebook (any prefix-free code): shared by the workgroup.
 struct DecTables {
@@ -59,22 +60,41 @@ struct ChunkTables {
     }
 };
 
+// The bit window of a lane: `win` holds the buffered bits MSB-aligned, `room` = 32 - (number
+// of buffered bits); a lane asks for a word when room > 0.
+//
+// Decodes one symbol and returns its table entry (symbol << 8) | length; the callers pick the
+// symbol byte out with v_perm_b32 when they pack the output.
 template <class TAB>
-__device__ __forceinline__ uint32_t decode_one(u64& win, int& nb, const TAB& T, uint32_t* err) {
+__device__ __forceinline__ uint32_t decode_one(u64& win, int& room, const TAB& T, uint32_t* err) {
     const uint32_t top = (uint32_t)(win >> 32);
-    const uint32_t e = T.lut[top >> (32 - HF_LUT_BITS)];
-    uint32_t len = e & 0xFFu;
-    uint32_t sym = e >> 8;
-    if (__builtin_expect(len == 0, 0)) {
-        sym = T.long_code(top, sym, len);
+    uint32_t e = T.lut[top >> (32 - HF_LUT_BITS)];
+    if (__builtin_expect((e & 0xFFu) == 0, 0)) {
+        uint32_t len;
+        const uint32_t sym = T.long_code(top, e >> 8, len);
         if (len == 0) {  // no code matches: flag it and keep moving
             atomicOr(err, HF_KERR_CORRUPT);
             len = 1;
         }
+        e = (sym << 8) | len;
     }
-    win <<= len;
-    nb -= (int)len;
-    return sym;
+    win <<= (e & 63u);  // lengths are <= 16; the 64-bit shift reads only these six bits
+    room += (int)(e & 0xFFu);
+    return e;
+}
+
+// A wave-uniform global pointer moved into scalar registers (address space 1 = global memory).
+typedef __attribute__((address_space(1))) uint8_t gmem_u8;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) u32x2 gmem_u32x2;
+typedef __attribute__((address_space(1))) u32x4 gmem_u32x4;
+__device__ __forceinline__ gmem_u8* uniform_ptr(const void* p) {
+    const u64 v = (u64)p;
+    // the builtin returns int: both halves go through uint32_t so that none is sign-extended
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    return (gmem_u8*)(((u64)hi << 32) | (u64)lo);
 }
 
 // Copy payload words [gs, gs + kStageWords) into the wavefront's LDS window; gs is a multiple
@@ -98,16 +118,20 @@ __device__ __forceinline__ void stage_window(const uint32_t* __restrict__ payloa
 }
 
 // refill step shared by both paths: lanes in `need` take consecutive words from the window
-__device__ __forceinline__ void refill(const bool need, u64& win, int& nb, uint32_t& lpos,
+__device__ __forceinline__ void refill(const bool need, u64& win, int& room, uint32_t& lpos,
                                        const uint32_t* __restrict__ stg) {
     const u64 m = __ballot(need);
     if (m != 0) {  // wave-uniform
-        uint32_t idx = lpos + hf_mbcnt(m);
-        idx = idx < (uint32_t)kStageWords ? idx : (uint32_t)kStageWords - 1u;
+        // window index = lpos + (needing lanes below this one); v_mbcnt accumulates onto the
+        // base.  A well-formed chunk never moves lpos past the staged words; the scalar clamp
+        // plus the kStageSlack words behind the window keep a corrupt one inside the array.
+        const uint32_t base = lpos < (uint32_t)kStageWords ? lpos : (uint32_t)kStageWords;
+        const uint32_t idx = __builtin_amdgcn_mbcnt_hi(
+            (uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, base));
         const uint32_t w = stg[idx];
-        if (need) {
-            win |= (u64)w << (32 - nb);
-            nb += 32;
+        if (need) {  // 1 <= room <= 32 here
+            win |= (u64)w << (room & 63);
+            room -= 32;
         }
         lpos += (uint32_t)__popcll(m);
     }
@@ -124,48 +148,61 @@ __device__ u64 decode_chunk_full(const uint32_t* __restrict__ payload, const u64
     stage_window(payload, payload_words, gs, stg, lane);
     uint32_t lpos = (uint32_t)(off0 - gs);  // window index of the next unread word
     u64 win = 0;                            // buffered bits, MSB aligned
-    int nb = 0;
+    int room = 32;                          // 32 - buffered bit count
 
-    const uint2* side2 = reinterpret_cast<const uint2*>(side_chunk);
+    // chunk bases as scalar registers: each round adds a scalar offset, the lane's part stays a
+    // constant 32-bit vector offset, and no per-round vector address arithmetic is left
+    const gmem_u8* const su = uniform_ptr(side_chunk);
+    gmem_u8* const ou = uniform_ptr(out_chunk);
+    const uint32_t lane8 = (uint32_t)lane * 8u, lane16 = (uint32_t)lane * 16u;
     // side bytes of even rounds live in sdA, of odd rounds in sdB; each is reloaded for two
     // rounds ahead right after its use, so no register is rotated and every wait is counted
-    uint2 sdA = make_uint2(0, 0), sdB = make_uint2(0, 0);
+    u32x2 sdA = {0u, 0u}, sdB = {0u, 0u};
     if (LAYOUT == HF_LAYOUT_BF16_EXP) {
-        sdA = side2[lane];
-        sdB = side2[64 + lane];
+        sdA = *reinterpret_cast<const gmem_u32x2*>(su + lane8);
+        sdB = *reinterpret_cast<const gmem_u32x2*>(su + 512 + lane8);
     }
-    auto round = [&](const uint32_t r, uint2& sd) {
-        const uint32_t g = r * 64u + lane;
+    auto round = [&](const uint32_t r, u32x2& sd) {
         // a round takes at most 4 x 64 words: slide the window when it could run out
         if (lpos + 256u > (uint32_t)kStageWords && gs + kStageWords < off1) {
             gs = (gs + lpos) & ~3ull;
             lpos = lpos & 3u;
             stage_window(payload, payload_words, gs, stg, lane);
         }
-        uint32_t s[8];
+        uint32_t e[8];  // table entries: symbol in byte 1
 #pragma unroll
         for (int jp = 0; jp < 4; ++jp) {
-            refill(nb < 32, win, nb, lpos, stg);
-            s[2 * jp] = decode_one(win, nb, T, err);
-            s[2 * jp + 1] = decode_one(win, nb, T, err);
+            refill(room > 0, win, room, lpos, stg);
+            e[2 * jp] = decode_one(win, room, T, err);
+            e[2 * jp + 1] = decode_one(win, room, T, err);
         }
         if (LAYOUT == HF_LAYOUT_BF16_EXP) {
+            // two bf16 per dword with packed operations (v_perm_b32; selector byte 0x0C reads
+            // as zero): the exponents and the side bytes go to bytes 0 and 2, then the sign
+            // moves from bit 7 to bit 15 of each half and the exponent slots in at bit 7
+            // sign move: with x = t & 0x00800080, t + 255 * x clears bit 7 and sets bit 15
             uint32_t o[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const uint32_t h = (i < 2 ? sd.x : sd.y) >> (16 * (i & 1));
-                const uint32_t b0 = h & 0xFFu, b1 = (h >> 8) & 0xFFu;
-                const uint32_t w0 = ((b0 & 0x80u) << 8) | (s[2 * i] << 7) | (b0 & 0x7Fu);
-                const uint32_t w1 = ((b1 & 0x80u) << 8) | (s[2 * i + 1] << 7) | (b1 & 0x7Fu);
-                o[i] = w0 | (w1 << 16);
+                const uint32_t t = __builtin_amdgcn_perm(0u, i < 2 ? sd.x : sd.y,
+                                                         (i & 1) ? 0x0C030C02u : 0x0C010C00u);
+                const uint32_t expo = __builtin_amdgcn_perm(e[2 * i + 1], e[2 * i], 0x0C050C01u);
+                // the two three-operand forms are spelled out: the compiler splits them otherwise
+                uint32_t sm;
+                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(sm) : "v"(t & 0x00800080u), "s"(255u), "v"(t));
+                asm("v_lshl_or_b32 %0, %1, 7, %2" : "=v"(o[i]) : "v"(expo), "v"(sm));
             }
-            const uint32_t g2 = g + 128u < HF_ROUNDS * 64u ? g + 128u : g;  // stay inside the chunk
-            sd = side2[g2];
-            reinterpret_cast<uint4*>(out_chunk)[g] = make_uint4(o[0], o[1], o[2], o[3]);
+            // side bytes for two rounds ahead; the last two rounds reload round 31's
+            const uint32_t pf = r + 2u < HF_ROUNDS ? r + 2u : HF_ROUNDS - 1u;
+            sd = *reinterpret_cast<const gmem_u32x2*>(su + pf * 512u + lane8);
+            *reinterpret_cast<gmem_u32x4*>(ou + r * 1024u + lane16) = u32x4{o[0], o[1], o[2], o[3]};
         } else {
-            const uint32_t o0 = s[0] | (s[1] << 8) | (s[2] << 16) | (s[3] << 24);
-            const uint32_t o1 = s[4] | (s[5] << 8) | (s[6] << 16) | (s[7] << 24);
-            reinterpret_cast<uint2*>(out_chunk)[g] = make_uint2(o0, o1);
+            const uint32_t a = __builtin_amdgcn_perm(e[1], e[0], 0x0C0C0501u);
+            const uint32_t b = __builtin_amdgcn_perm(e[3], e[2], 0x0C0C0501u);
+            const uint32_t c = __builtin_amdgcn_perm(e[5], e[4], 0x0C0C0501u);
+            const uint32_t d = __builtin_amdgcn_perm(e[7], e[6], 0x0C0C0501u);
+            *reinterpret_cast<gmem_u32x2*>(ou + r * 512u + lane8) =
+                u32x2{a | (b << 16), c | (d << 16)};
         }
     };
     for (uint32_t r = 0; r < HF_ROUNDS; r += 2) {
@@ -187,7 +224,7 @@ __device__ u64 decode_chunk_tail(const uint32_t* __restrict__ payload, const u64
     stage_window(payload, payload_words, gs, stg, lane);
     uint32_t lpos = (uint32_t)(off0 - gs);
     u64 win = 0;
-    int nb = 0;
+    int room = 32;
     const uint32_t rounds = (nvalid + 511u) / 512u;
     for (uint32_t r = 0; r < rounds; ++r) {
         const uint32_t g = r * 64u + lane;
@@ -201,9 +238,9 @@ __device__ u64 decode_chunk_tail(const uint32_t* __restrict__ payload, const u64
         for (int jp = 0; jp < 4; ++jp) {
             const uint32_t i0 = g * 8 + 2 * jp;
             const bool va = i0 < nvalid, vb = i0 + 1 < nvalid;
-            refill(va && nb < 32, win, nb, lpos, stg);
-            s[2 * jp] = va ? decode_one(win, nb, T, err) : 0u;
-            s[2 * jp + 1] = vb ? decode_one(win, nb, T, err) : 0u;
+            refill(va && room > 0, win, room, lpos, stg);
+            s[2 * jp] = va ? decode_one(win, room, T, err) >> 8 : 0u;
+            s[2 * jp + 1] = vb ? decode_one(win, room, T, err) >> 8 : 0u;
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -228,7 +265,7 @@ __global__ __launch_bounds__(kWaves * 64) void hf_k_decode(
     const uint32_t nchunks, const hf_cb_dev* __restrict__ cb, void* __restrict__ out,
     uint32_t* err) {
     __shared__ __attribute__((aligned(16))) DecTables T;
-    __shared__ __attribute__((aligned(16))) uint32_t stage[kWaves][kStageWords];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[kWaves][kStageWords + kStageSlack];
     {
         const uint4* src = reinterpret_cast<const uint4*>(cb->lut);
         uint4* dst = reinterpret_cast<uint4*>(T.lut);
@@ -362,7 +399,7 @@ __global__ __launch_bounds__(kWavesC * 64) void hf_k_decode_chunks(
     const uint32_t* __restrict__ chunk_ids, const uint32_t n_work, void* __restrict__ out,
     uint32_t* err) {
     __shared__ __attribute__((aligned(16))) uint16_t lut_all[kWavesC][HF_LUT_SIZE];
-    __shared__ __attribute__((aligned(16))) uint32_t stage[kWavesC][kStageWords];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[kWavesC][kStageWords + kStageSlack];
     __shared__ __attribute__((aligned(16))) uint32_t tmp_all[kWavesC][256];
     __shared__ __attribute__((aligned(16))) uint8_t r2s_all[kWavesC][256];
     const int lane = hf_lane();

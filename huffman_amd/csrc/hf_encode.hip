@@ -346,8 +346,11 @@ __global__ __launch_bounds__(kWaves * 64) void hf_k_encode(
         // the prefix is the same in every lane: keep it in scalar registers so the branches
         // below are plain scalar branches
         const u64 tb = tile_base;
-        const u64 base = (((u64)__builtin_amdgcn_readfirstlane((uint32_t)(tb >> 32)) << 32) |
-                          (u64)__builtin_amdgcn_readfirstlane((uint32_t)tb)) + my_off;
+        // (the builtin returns int: the halves pass through uint32_t, or the low one would be
+        // sign-extended over the high one once the payload passes 2^31 words)
+        const uint32_t tb_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tb >> 32));
+        const uint32_t tb_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tb);
+        const u64 base = (((u64)tb_hi << 32) | (u64)tb_lo) + my_off;
         if (c < nchunks) {
             if (lane == 0) {
                 chunk_off[c] = (uint32_t)base;
