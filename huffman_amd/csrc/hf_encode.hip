@@ -219,9 +219,11 @@ __device__ __forceinline__ void encode_round(const uint32_t (&raw)[4], const uin
     }
 }
 
-// One chunk.  Returns the number of payload words (wave-uniform).
+// One chunk.  Returns the number of payload words (wave-uniform).  Always inlined: as a called
+// function its table and staging pointers would be generic ones, and every LDS access a flat
+// access whose wait also drains the input loads in flight.
 template <int LAYOUT, bool FULL>
-__device__ uint32_t encode_chunk(const void* chunk_in, const uint32_t nvalid,
+__device__ __forceinline__ uint32_t encode_chunk(const void* chunk_in, const uint32_t nvalid,
                                  const uint32_t* __restrict__ enc, uint32_t* __restrict__ stg,
                                  uint32_t* __restrict__ spill, uint8_t* side_chunk,
                                  const int lane) {
