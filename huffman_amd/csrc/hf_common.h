@@ -131,4 +131,22 @@ __device__ __forceinline__ uint32_t hf_mbcnt(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
                                      __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
+
+// Global-memory (address space 1) views used by the streaming kernels: with a chunk's base held
+// in scalar registers, a per-round scalar offset and a constant per-lane vector offset, an access
+// needs no vector address arithmetic.
+typedef __attribute__((address_space(1))) uint8_t hf_gmem_u8;
+typedef uint32_t hf_u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t hf_u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) hf_u32x2 hf_gmem_u32x2;
+typedef __attribute__((address_space(1))) hf_u32x4 hf_gmem_u32x4;
+
+// A wave-uniform global pointer moved into scalar registers.  The builtin returns int: both
+// halves go through uint32_t so that the low one is not sign-extended over the high one.
+__device__ __forceinline__ hf_gmem_u8* hf_uniform_ptr(const void* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    return (hf_gmem_u8*)(((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
 #endif

@@ -83,20 +83,6 @@ __device__ __forceinline__ uint32_t decode_one(u64& win, int& room, const TAB& T
     return e;
 }
 
-// A wave-uniform global pointer moved into scalar registers (address space 1 = global memory).
-typedef __attribute__((address_space(1))) uint8_t gmem_u8;
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(1))) u32x2 gmem_u32x2;
-typedef __attribute__((address_space(1))) u32x4 gmem_u32x4;
-__device__ __forceinline__ gmem_u8* uniform_ptr(const void* p) {
-    const u64 v = (u64)p;
-    // the builtin returns int: both halves go through uint32_t so that none is sign-extended
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32));
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-    return (gmem_u8*)(((u64)hi << 32) | (u64)lo);
-}
-
 // Copy payload words [gs, gs + kStageWords) into the wavefront's LDS window; gs is a multiple
 // of 4 so every access is a 16-byte one.  Words past the payload buffer read as zero.
 __device__ __forceinline__ void stage_window(const uint32_t* __restrict__ payload,
@@ -152,17 +138,17 @@ __device__ u64 decode_chunk_full(const uint32_t* __restrict__ payload, const u64
 
     // chunk bases as scalar registers: each round adds a scalar offset, the lane's part stays a
     // constant 32-bit vector offset, and no per-round vector address arithmetic is left
-    const gmem_u8* const su = uniform_ptr(side_chunk);
-    gmem_u8* const ou = uniform_ptr(out_chunk);
+    const hf_gmem_u8* const su = hf_uniform_ptr(side_chunk);
+    hf_gmem_u8* const ou = hf_uniform_ptr(out_chunk);
     const uint32_t lane8 = (uint32_t)lane * 8u, lane16 = (uint32_t)lane * 16u;
     // side bytes of even rounds live in sdA, of odd rounds in sdB; each is reloaded for two
     // rounds ahead right after its use, so no register is rotated and every wait is counted
-    u32x2 sdA = {0u, 0u}, sdB = {0u, 0u};
+    hf_u32x2 sdA = {0u, 0u}, sdB = {0u, 0u};
     if (LAYOUT == HF_LAYOUT_BF16_EXP) {
-        sdA = *reinterpret_cast<const gmem_u32x2*>(su + lane8);
-        sdB = *reinterpret_cast<const gmem_u32x2*>(su + 512 + lane8);
+        sdA = *reinterpret_cast<const hf_gmem_u32x2*>(su + lane8);
+        sdB = *reinterpret_cast<const hf_gmem_u32x2*>(su + 512 + lane8);
     }
-    auto round = [&](const uint32_t r, u32x2& sd) {
+    auto round = [&](const uint32_t r, hf_u32x2& sd) {
         // a round takes at most 4 x 64 words: slide the window when it could run out
         if (lpos + 256u > (uint32_t)kStageWords && gs + kStageWords < off1) {
             gs = (gs + lpos) & ~3ull;
@@ -194,15 +180,15 @@ __device__ u64 decode_chunk_full(const uint32_t* __restrict__ payload, const u64
             }
             // side bytes for two rounds ahead; the last two rounds reload round 31's
             const uint32_t pf = r + 2u < HF_ROUNDS ? r + 2u : HF_ROUNDS - 1u;
-            sd = *reinterpret_cast<const gmem_u32x2*>(su + pf * 512u + lane8);
-            *reinterpret_cast<gmem_u32x4*>(ou + r * 1024u + lane16) = u32x4{o[0], o[1], o[2], o[3]};
+            sd = *reinterpret_cast<const hf_gmem_u32x2*>(su + pf * 512u + lane8);
+            *reinterpret_cast<hf_gmem_u32x4*>(ou + r * 1024u + lane16) = hf_u32x4{o[0], o[1], o[2], o[3]};
         } else {
             const uint32_t a = __builtin_amdgcn_perm(e[1], e[0], 0x0C0C0501u);
             const uint32_t b = __builtin_amdgcn_perm(e[3], e[2], 0x0C0C0501u);
             const uint32_t c = __builtin_amdgcn_perm(e[5], e[4], 0x0C0C0501u);
             const uint32_t d = __builtin_amdgcn_perm(e[7], e[6], 0x0C0C0501u);
-            *reinterpret_cast<gmem_u32x2*>(ou + r * 512u + lane8) =
-                u32x2{a | (b << 16), c | (d << 16)};
+            *reinterpret_cast<hf_gmem_u32x2*>(ou + r * 512u + lane8) =
+                hf_u32x2{a | (b << 16), c | (d << 16)};
         }
     };
     for (uint32_t r = 0; r < HF_ROUNDS; r += 2) {

@@ -18,6 +18,8 @@
 // whose workgroups are already running.
 //
 // HBM traffic per bf16 element: 2 B read, 1 B side stream written, ~L/8 B payload written.
+#include <type_traits>
+
 #include "hf_common.h"
 
 namespace {
@@ -28,6 +30,7 @@ constexpr int kWaves = 4;            // wavefronts per workgroup
 constexpr int kStgWords = 4224;      // LDS staging per wavefront (16.5 KiB: 8 bits/symbol + slack)
 constexpr int kMaxChunkWords = 129 * 64;                  // 128 code words + 1 look-ahead, per lane
 constexpr int kSpillWords = kMaxChunkWords - kStgWords;   // global spill per wavefront slot
+constexpr int kDepth = 8;            // input groups (rounds) a wavefront keeps in flight
 
 constexpr u64 kDescAggregate = 1ull << 62;
 constexpr u64 kDescPrefix = 2ull << 62;
@@ -135,8 +138,16 @@ struct LaneState {
 // Lanes with `done` place word `w` in slot `slot`.  The LDS path is a plain predicated
 // ds_write; the global spill area is only touched under a wave-uniform branch, so the common
 // path carries no pointer selection.
+//
+// CHECK = false: the caller has established (from the wave-uniform slot counter) that every
+// slot in play lies inside the LDS staging area, and the test disappears.
+template <bool CHECK = true>
 __device__ __forceinline__ void put_word(const bool done, const uint32_t slot, const uint32_t w,
                                          uint32_t* __restrict__ stg, uint32_t* __restrict__ spill) {
+    if (!CHECK) {
+        if (done) stg[slot] = w;
+        return;
+    }
     const bool in_lds = slot < (uint32_t)kStgWords;
     if (done && in_lds) stg[slot] = w;
     if (__builtin_expect(__any(done && !in_lds), 0)) {
@@ -146,29 +157,35 @@ __device__ __forceinline__ void put_word(const bool done, const uint32_t slot, c
 
 // One round of one lane: 8 symbols out of `raw`, side bytes stored, codes looked up, the
 // decoder's refill schedule replayed and completed words placed.
-template <int LAYOUT, bool FULL>
+template <int LAYOUT, bool FULL, bool CHECK>
 __device__ __forceinline__ void encode_round(const uint32_t (&raw)[4], const uint32_t g,
                                              const uint32_t nvalid, LaneState& st,
                                              const uint32_t* __restrict__ enc,
                                              uint32_t* __restrict__ stg,
-                                             uint32_t* __restrict__ spill, uint8_t* side_chunk) {
+                                             uint32_t* __restrict__ spill, uint8_t* side_chunk,
+                                             hf_gmem_u8* side_row) {
     uint32_t s[8];
     if (LAYOUT == HF_LAYOUT_BF16_EXP) {
-        uint32_t t[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t d = raw[i];
             s[2 * i] = (d >> 7) & 0xFFu;
             s[2 * i + 1] = (d >> 23) & 0xFFu;
-            // both side bytes of the dword at once: sign bit into bit 7, mantissa below it;
-            // they land in bytes 0 and 2 of t
-            t[i] = ((d >> 8) & 0x00800080u) | (d & 0x007F007Fu);
         }
-        // gather bytes 0 and 2 of two dwords into one (v_perm_b32)
+        // side bytes of four elements at once: v_perm_b32 gathers their low bytes (mantissa
+        // under the exponent's last bit) and their high bytes (sign over exponent bits), one
+        // bit-select keeps the mantissas of the first and the signs of the second
         uint32_t sd[2];
-        sd[0] = __builtin_amdgcn_perm(t[1], t[0], 0x06040200u);
-        sd[1] = __builtin_amdgcn_perm(t[3], t[2], 0x06040200u);
-        if (FULL || (g * 8 + 8 <= nvalid)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t lo = __builtin_amdgcn_perm(raw[2 * h + 1], raw[2 * h], 0x06040200u);
+            const uint32_t hi = __builtin_amdgcn_perm(raw[2 * h + 1], raw[2 * h], 0x07050301u);
+            // (lo & mask) | (hi & ~mask), spelled out: the compiler splits it in three
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(sd[h]) : "s"(0x7F7F7F7Fu), "v"(lo), "v"(hi));
+        }
+        if (FULL) {
+            *reinterpret_cast<hf_gmem_u32x2*>(side_row) = hf_u32x2{sd[0], sd[1]};
+        } else if (g * 8 + 8 <= nvalid) {
             reinterpret_cast<uint2*>(side_chunk)[g] = make_uint2(sd[0], sd[1]);
         } else {
 #pragma unroll
@@ -203,17 +220,25 @@ __device__ __forceinline__ void encode_round(const uint32_t (&raw)[4], const uin
         const bool need = active && st.nb < 32;
         const u64 m = __ballot(need);
         const uint32_t p = st.pos + hf_mbcnt(m);
-        const bool empty = (st.nb + (int)st.ab) == 0;  // no slot pending
+        // no slot pending <=> nb + ab == 0 <=> nb == 0 (ab < 32 and the sum is a multiple of 32)
+        const bool empty = st.nb == 0;
         st.p1 = need ? p : st.p1;                      // the newest slot
-        st.p0 = (need && empty) ? p : st.p0;           // the oldest slot
-        st.nb += (need ? 32 : 0) - (int)cl;
+        if (FULL) {
+            // an empty lane always needs a word, and 0 <= nb < 64 makes (nb | 32) the count
+            // after the refill whether or not one happened
+            st.p0 = empty ? p : st.p0;
+            st.nb = (st.nb | 32) - (int)cl;
+        } else {
+            st.p0 = (need && empty) ? p : st.p0;       // the oldest slot
+            st.nb += (need ? 32 : 0) - (int)cl;
+        }
         st.pos += (uint32_t)__popcll(m);
 
         // pack: append the pair, emit the oldest pending word once 32 bits are complete
         st.acc = (st.acc << cl) | (u64)comb;
         st.ab += cl;
         const bool done = st.ab >= 32;
-        put_word(done, st.p0, (uint32_t)(st.acc >> (st.ab & 31u)), stg, spill);
+        put_word<CHECK>(done, st.p0, (uint32_t)(st.acc >> (st.ab & 31u)), stg, spill);
         st.p0 = done ? st.p1 : st.p0;
         st.ab &= 31u;
     }
@@ -222,31 +247,70 @@ __device__ __forceinline__ void encode_round(const uint32_t (&raw)[4], const uin
 // One chunk.  Returns the number of payload words (wave-uniform).  Always inlined: as a called
 // function its table and staging pointers would be generic ones, and every LDS access a flat
 // access whose wait also drains the input loads in flight.
+// Round r of a full chunk: the 8 symbols of group r * 64 + lane.  `gin` is the chunk's base in
+// scalar registers; round r adds a scalar offset, the lane's share is a constant vector offset.
+template <int LAYOUT>
+__device__ __forceinline__ void load_round(const hf_gmem_u8* gin, const uint32_t r, const int lane,
+                                           uint32_t (&b)[4]) {
+    if (LAYOUT == HF_LAYOUT_BF16_EXP) {
+        const hf_u32x4 v =
+            *reinterpret_cast<const hf_gmem_u32x4*>(gin + r * 1024u + (uint32_t)lane * 16u);
+        b[0] = v.x, b[1] = v.y, b[2] = v.z, b[3] = v.w;
+    } else {
+        const hf_u32x2 v =
+            *reinterpret_cast<const hf_gmem_u32x2*>(gin + r * 512u + (uint32_t)lane * 8u);
+        b[0] = v.x, b[1] = v.y, b[2] = b[3] = 0;
+    }
+}
+
+// Issue the loads of the first kDepth rounds of a full chunk.
+template <int LAYOUT>
+__device__ __forceinline__ void preload_chunk(const void* chunk_in, const int lane,
+                                              uint32_t (&buf)[kDepth][4]) {
+    const hf_gmem_u8* const gin = hf_uniform_ptr(chunk_in);
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d) load_round<LAYOUT>(gin, (uint32_t)d, lane, buf[d]);
+}
+
+// `buf` holds (or has loads in flight for) the first kDepth rounds when FULL.
 template <int LAYOUT, bool FULL>
 __device__ __forceinline__ uint32_t encode_chunk(const void* chunk_in, const uint32_t nvalid,
                                  const uint32_t* __restrict__ enc, uint32_t* __restrict__ stg,
                                  uint32_t* __restrict__ spill, uint8_t* side_chunk,
-                                 const int lane) {
+                                 const int lane, uint32_t (&buf)[kDepth][4]) {
     LaneState st;
     if (FULL) {
         // Input groups are fetched kDepth rounds ahead into kDepth named register sets; a set
         // is refilled right after its symbols are extracted, so no register is copied and the
         // compiler's waits stay counted.  With two wavefronts per SIMD this depth is what keeps
         // enough bytes in flight to cover HBM latency.
-        constexpr int kDepth = 8;
-        uint32_t buf[kDepth][4];
-#pragma unroll
-        for (int d = 0; d < kDepth; ++d)
-            load_group<LAYOUT, true>(chunk_in, (uint32_t)(d * 64 + lane), nvalid, buf[d]);
+        const hf_gmem_u8* const gin = hf_uniform_ptr(chunk_in);
+        hf_gmem_u8* const gside = hf_uniform_ptr(side_chunk);
+        const uint32_t lane8 = (uint32_t)lane * 8u;
         for (uint32_t r0 = 0; r0 < HF_ROUNDS; r0 += kDepth) {
 #pragma unroll
-            for (int d = 0; d < kDepth; ++d) {
-                const uint32_t g = (r0 + d) * 64u + lane;
-                uint32_t raw[4] = {buf[d][0], buf[d][1], buf[d][2], buf[d][3]};
-                // refill this set for round r + kDepth (the last rounds re-read their own group)
-                const uint32_t gn = r0 + d + kDepth < HF_ROUNDS ? g + kDepth * 64u : g;
-                load_group<LAYOUT, true>(chunk_in, gn, nvalid, buf[d]);
-                encode_round<LAYOUT, true>(raw, g, nvalid, st, enc, stg, spill, side_chunk);
+            for (int h = 0; h < kDepth; h += 4) {
+                // four rounds hand out at most 4 x 256 slots and every pending slot is below
+                // the counter: if they all fit the staging area no per-word test is needed
+                const bool fits = st.pos + 1024u <= (uint32_t)kStgWords;  // wave-uniform
+                auto four = [&](auto check) {
+#pragma unroll
+                    for (int d = h; d < h + 4; ++d) {
+                        const uint32_t r = r0 + d;
+                        uint32_t raw[4] = {buf[d][0], buf[d][1], buf[d][2], buf[d][3]};
+                        // refill this set for round r + kDepth (the last rounds re-read their
+                        // own group)
+                        load_round<LAYOUT>(gin, r + kDepth < HF_ROUNDS ? r + kDepth : r, lane,
+                                           buf[d]);
+                        encode_round<LAYOUT, true, decltype(check)::value>(
+                            raw, r * 64u + lane, nvalid, st, enc, stg, spill, side_chunk,
+                            gside + r * 512u + lane8);
+                    }
+                };
+                if (fits)
+                    four(std::false_type{});
+                else
+                    four(std::true_type{});
             }
         }
     } else {
@@ -255,7 +319,8 @@ __device__ __forceinline__ uint32_t encode_chunk(const void* chunk_in, const uin
             const uint32_t g = r * 64u + lane;
             uint32_t raw[4];
             load_group<LAYOUT, false>(chunk_in, g, nvalid, raw);
-            encode_round<LAYOUT, false>(raw, g, nvalid, st, enc, stg, spill, side_chunk);
+            encode_round<LAYOUT, false, true>(raw, g, nvalid, st, enc, stg, spill, side_chunk,
+                                              nullptr);
         }
     }
     // words asked for but not filled: the zero-padded last word, then an all-zero word
@@ -264,6 +329,15 @@ __device__ __forceinline__ uint32_t encode_chunk(const void* chunk_in, const uin
     put_word(pending > 1, st.p1, 0u, stg, spill);
     return st.pos;
 }
+
+template <bool PER_CHUNK>
+struct EncLds {
+    uint32_t enc[PER_CHUNK ? kWaves * 256 : 256];
+    uint32_t stg[kWaves][kStgWords];
+    u64 base;
+    uint32_t tot[kWaves];
+    uint32_t ticket;
+};
 
 // PER_CHUNK = false: one codebook (hf_cb_dev) for the whole stream, its encoder table shared
 // by the workgroup.  PER_CHUNK = true: chunk c is coded with record c of an hf_chunk_cb array
@@ -274,14 +348,16 @@ __global__ __launch_bounds__(kWaves * 64) void hf_k_encode(
     const void* __restrict__ cbv, uint8_t* __restrict__ side, uint32_t* __restrict__ payload,
     const uint64_t cap_words, uint32_t* __restrict__ chunk_off, u64* desc, uint32_t* ticket,
     uint32_t* spill_base, uint32_t* err) {
-    __shared__ uint32_t enc_all[PER_CHUNK ? kWaves * 256 : 256];
-    __shared__ uint32_t stg_all[kWaves][kStgWords];
-    __shared__ uint32_t tile_ticket;
-    __shared__ uint32_t tile_tot[kWaves];
-    __shared__ u64 tile_base;
+    // one object, so that the encoder table sits at LDS address 0 and a lookup's address is the
+    // symbol times four with nothing added
+    __shared__ EncLds<PER_CHUNK> L;
+    uint32_t(&stg_all)[kWaves][kStgWords] = L.stg;
+    uint32_t(&tile_tot)[kWaves] = L.tot;
+    uint32_t& tile_ticket = L.ticket;
+    u64& tile_base = L.base;
     if (!PER_CHUNK)
-        enc_all[threadIdx.x] = reinterpret_cast<const hf_cb_dev*>(cbv)->enc[threadIdx.x];
-    uint32_t* enc = PER_CHUNK ? enc_all + (threadIdx.x >> 6) * 256 : enc_all;
+        L.enc[threadIdx.x] = reinterpret_cast<const hf_cb_dev*>(cbv)->enc[threadIdx.x];
+    uint32_t* enc = PER_CHUNK ? L.enc + (threadIdx.x >> 6) * 256 : L.enc;
 
     const int lane = hf_lane();
     const int wave = threadIdx.x >> 6;
@@ -316,12 +392,15 @@ __global__ __launch_bounds__(kWaves * 64) void hf_k_encode(
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-            if (nvalid == HF_CHUNK_SYMS)
+            uint32_t buf[kDepth][4];
+            if (nvalid == HF_CHUNK_SYMS) {
+                preload_chunk<LAYOUT>(chunk_in, lane, buf);
                 total = encode_chunk<LAYOUT, true>(chunk_in, nvalid, enc, stg, spill, side_chunk,
-                                                   lane);
-            else
+                                                   lane, buf);
+            } else {
                 total = encode_chunk<LAYOUT, false>(chunk_in, nvalid, enc, stg, spill, side_chunk,
-                                                    lane);
+                                                    lane, buf);
+            }
             total = __builtin_amdgcn_readfirstlane(total);
         }
         if (lane == 0) tile_tot[wave] = total;
