@@ -392,10 +392,21 @@ __global__ __launch_bounds__(64) void hf_k_system(const u64* __restrict__ freq25
             cb->len[s] = (uint8_t)L.adj[p];
         }
     }
+    // expected payload of a full chunk: 16384 symbols x mean code length, in 32-bit words, plus
+    // the two look-ahead words each of the 64 lanes may leave behind
+    u64 bits = 0, cnt = 0;
+    for (int p = lane; p < N; p += 64) {
+        const u64 f = sorted[p];
+        bits += f * (mode == HF_MODE_BYPASS ? 8ull : (u64)L.adj[p]);
+        cnt += f;
+    }
+    bits = hf_wave_sum_u64(bits);
+    cnt = hf_wave_sum_u64(cnt);
     if (lane == 0) {
         cb->mode = mode;
         cb->entropy_q16 = ent;
         cb->entropy_mode = emode;
+        cb->chunk_words_hint = cnt ? (uint32_t)(bits * (HF_CHUNK_SYMS / 32) / cnt) + 128u : 0u;
     }
 }
 

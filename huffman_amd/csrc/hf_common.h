@@ -27,7 +27,9 @@ struct hf_cb_dev {
     uint32_t entropy_q16;
     uint32_t entropy_mode;       // what the entropy decision alone says
     uint32_t max_len;
-    uint32_t pad[3];
+    uint32_t chunk_words_hint;   // payload words a full chunk is expected to take (symbol counts
+                                 // x code lengths, schedule overhead included); 0 = unknown
+    uint32_t pad[2];
 };
 static_assert(sizeof(hf_cb_dev) <= HF_CODEBOOK_DEV_BYTES, "codebook struct outgrew its slot");
 

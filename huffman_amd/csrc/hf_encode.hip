@@ -29,7 +29,9 @@ typedef unsigned long long u64;
 constexpr int kWaves = 4;            // wavefronts per workgroup
 constexpr int kStgWords = 4224;      // LDS staging per wavefront (16.5 KiB: 8 bits/symbol + slack)
 constexpr int kMaxChunkWords = 129 * 64;                  // 128 code words + 1 look-ahead, per lane
-constexpr int kSpillWords = kMaxChunkWords - kStgWords;   // global spill per wavefront slot
+constexpr int kHalfWords = kStgWords / 2;                 // staging of one chunk when two are kept
+constexpr int kSpillWords = kMaxChunkWords - kHalfWords;  // global spill per staged chunk
+constexpr int kPipeMargin = 192;     // expected chunk size must stay this far below kHalfWords
 constexpr int kDepth = 8;            // input groups (rounds) a wavefront keeps in flight
 
 constexpr u64 kDescAggregate = 1ull << 62;
@@ -37,40 +39,57 @@ constexpr u64 kDescPrefix = 2ull << 62;
 constexpr u64 kDescValueMask = (1ull << 62) - 1ull;
 constexpr u64 kSpinTicks = 100000000ull;  // 1 s
 
-// Exclusive prefix (in words) of tile t over the tile descriptors.  Each pass inspects the 128
-// tiles before the current position, two per lane (lane j: idx - j and idx - 64 - j); the
-// nearest descriptor holding an inclusive prefix ends the walk.  A descriptor is one 8-byte
-// {status, value} word written by a single agent-scope store, so a reader never needs more
-// than the word itself.
+constexpr int kLookK = 2;  // descriptors per lane and pass: a pass covers 128 tiles
+
+// Exclusive prefix (in words) of tile t over the tile descriptors.  Each pass inspects the
+// 64 * kLookK tiles before the current position, kLookK per lane (lane j, step k: tile
+// idx - 64 k - j), all loads in flight together; the nearest descriptor holding an inclusive
+// prefix ends the walk.
+// A descriptor is one 8-byte {status, value} word written by a single agent-scope store, so a
+// reader never needs more than the word itself.
 __device__ u64 lookback(const u64* desc, const uint32_t t, const int lane, uint32_t* err) {
     u64 excl = 0;
     long long idx = (long long)t - 1;
     uint32_t spins = 0;
     u64 t0 = 0;
     while (idx >= 0) {
-        const long long j0 = idx - lane, j1 = idx - 64 - lane;
+        u64 d[kLookK];
+#pragma unroll
+        for (int k = 0; k < kLookK; ++k) d[k] = 0;
         for (;;) {
-            // before tile 0: prefix 0
-            const u64 d0 = j0 >= 0 ? __hip_atomic_load(&desc[j0], __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT)
-                                   : kDescPrefix;
-            const u64 d1 = j1 >= 0 ? __hip_atomic_load(&desc[j1], __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT)
-                                   : kDescPrefix;
-            const u64 inv0 = __ballot((d0 >> 62) == 0), pre0 = __ballot((d0 >> 62) == 2);
-            const u64 inv1 = __ballot((d1 >> 62) == 0), pre1 = __ballot((d1 >> 62) == 2);
-            // position of the nearest prefix among the 128 (128 = none)
-            const int first = pre0 ? (int)__builtin_ctzll(pre0)
-                                   : (pre1 ? 64 + (int)__builtin_ctzll(pre1) : 128);
-            const int f0 = first < 63 ? first : 63;           // last near lane that counts
-            const int f1 = first < 64 ? -1 : (first - 64 < 63 ? first - 64 : 63);
-            const u64 upto0 = f0 >= 63 ? ~0ull : ((2ull << f0) - 1ull);
-            const u64 upto1 = f1 < 0 ? 0ull : (f1 >= 63 ? ~0ull : ((2ull << f1) - 1ull));
-            if (((inv0 & upto0) | (inv1 & upto1)) == 0) {
-                u64 v = lane <= f0 ? (d0 & kDescValueMask) : 0ull;
-                v += lane <= f1 ? (d1 & kDescValueMask) : 0ull;
+            // only descriptors not seen valid yet are (re)read: every workgroup of the grid polls
+            // the same few cache lines, and that traffic is what limits how fast they answer
+#pragma unroll
+            for (int k = 0; k < kLookK; ++k) {
+                const long long j = idx - 64 * k - lane;
+                if ((d[k] >> 62) == 0)  // before tile 0: prefix 0
+                    d[k] = j >= 0 ? __hip_atomic_load(&desc[j], __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT)
+                                  : kDescPrefix;
+            }
+            // nearest prefix: step kf, lane lf (kLookK = none); all descriptors nearer than it
+            // must hold at least an aggregate
+            int kf = kLookK, lf = 0;
+            bool holes = false;
+            u64 v = 0;
+#pragma unroll
+            for (int k = 0; k < kLookK; ++k) {
+                const u64 inv = __ballot((d[k] >> 62) == 0);
+                const u64 pre = __ballot((d[k] >> 62) == 2);
+                if (kf == kLookK) {  // still in front of the nearest prefix (wave-uniform)
+                    u64 upto = ~0ull;  // lanes that count in this step
+                    if (pre) {
+                        kf = k;
+                        lf = (int)__builtin_ctzll(pre);
+                        upto = lf >= 63 ? ~0ull : ((2ull << lf) - 1ull);
+                    }
+                    holes = holes || (inv & upto) != 0;
+                    v += ((upto >> lane) & 1ull) ? (d[k] & kDescValueMask) : 0ull;
+                }
+            }
+            if (!holes) {
                 excl += hf_wave_sum_u64(v);
-                if (first < 128) return excl;
+                if (kf < kLookK) return excl;
                 break;
             }
             // bounded wait: give up after kSpinTicks of the 100 MHz wall clock
@@ -82,9 +101,9 @@ __device__ u64 lookback(const u64* desc, const uint32_t t, const int lane, uint3
                     return excl;
                 }
             }
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(4);
         }
-        idx -= 128;
+        idx -= 64 * kLookK;
     }
     return excl;
 }
@@ -143,15 +162,16 @@ struct LaneState {
 // slot in play lies inside the LDS staging area, and the test disappears.
 template <bool CHECK = true>
 __device__ __forceinline__ void put_word(const bool done, const uint32_t slot, const uint32_t w,
-                                         uint32_t* __restrict__ stg, uint32_t* __restrict__ spill) {
+                                         uint32_t* __restrict__ stg, uint32_t* __restrict__ spill,
+                                         const uint32_t limit) {
     if (!CHECK) {
         if (done) stg[slot] = w;
         return;
     }
-    const bool in_lds = slot < (uint32_t)kStgWords;
+    const bool in_lds = slot < limit;
     if (done && in_lds) stg[slot] = w;
     if (__builtin_expect(__any(done && !in_lds), 0)) {
-        if (done && !in_lds) spill[slot - kStgWords] = w;
+        if (done && !in_lds) spill[slot - limit] = w;
     }
 }
 
@@ -162,8 +182,8 @@ __device__ __forceinline__ void encode_round(const uint32_t (&raw)[4], const uin
                                              const uint32_t nvalid, LaneState& st,
                                              const uint32_t* __restrict__ enc,
                                              uint32_t* __restrict__ stg,
-                                             uint32_t* __restrict__ spill, uint8_t* side_chunk,
-                                             hf_gmem_u8* side_row) {
+                                             uint32_t* __restrict__ spill, const uint32_t limit,
+                                             uint8_t* side_chunk, hf_gmem_u8* side_row) {
     uint32_t s[8];
     if (LAYOUT == HF_LAYOUT_BF16_EXP) {
 #pragma unroll
@@ -238,7 +258,7 @@ __device__ __forceinline__ void encode_round(const uint32_t (&raw)[4], const uin
         st.acc = (st.acc << cl) | (u64)comb;
         st.ab += cl;
         const bool done = st.ab >= 32;
-        put_word<CHECK>(done, st.p0, (uint32_t)(st.acc >> (st.ab & 31u)), stg, spill);
+        put_word<CHECK>(done, st.p0, (uint32_t)(st.acc >> (st.ab & 31u)), stg, spill, limit);
         st.p0 = done ? st.p1 : st.p0;
         st.ab &= 31u;
     }
@@ -276,8 +296,9 @@ __device__ __forceinline__ void preload_chunk(const void* chunk_in, const int la
 template <int LAYOUT, bool FULL>
 __device__ __forceinline__ uint32_t encode_chunk(const void* chunk_in, const uint32_t nvalid,
                                  const uint32_t* __restrict__ enc, uint32_t* __restrict__ stg,
-                                 uint32_t* __restrict__ spill, uint8_t* side_chunk,
-                                 const int lane, uint32_t (&buf)[kDepth][4]) {
+                                 uint32_t* __restrict__ spill, const uint32_t limit,
+                                 uint8_t* side_chunk, const int lane,
+                                 uint32_t (&buf)[kDepth][4]) {
     LaneState st;
     if (FULL) {
         // Input groups are fetched kDepth rounds ahead into kDepth named register sets; a set
@@ -292,7 +313,7 @@ __device__ __forceinline__ uint32_t encode_chunk(const void* chunk_in, const uin
             for (int h = 0; h < kDepth; h += 4) {
                 // four rounds hand out at most 4 x 256 slots and every pending slot is below
                 // the counter: if they all fit the staging area no per-word test is needed
-                const bool fits = st.pos + 1024u <= (uint32_t)kStgWords;  // wave-uniform
+                const bool fits = st.pos + 1024u <= limit;  // wave-uniform
                 auto four = [&](auto check) {
 #pragma unroll
                     for (int d = h; d < h + 4; ++d) {
@@ -303,7 +324,7 @@ __device__ __forceinline__ uint32_t encode_chunk(const void* chunk_in, const uin
                         load_round<LAYOUT>(gin, r + kDepth < HF_ROUNDS ? r + kDepth : r, lane,
                                            buf[d]);
                         encode_round<LAYOUT, true, decltype(check)::value>(
-                            raw, r * 64u + lane, nvalid, st, enc, stg, spill, side_chunk,
+                            raw, r * 64u + lane, nvalid, st, enc, stg, spill, limit, side_chunk,
                             gside + r * 512u + lane8);
                     }
                 };
@@ -319,14 +340,14 @@ __device__ __forceinline__ uint32_t encode_chunk(const void* chunk_in, const uin
             const uint32_t g = r * 64u + lane;
             uint32_t raw[4];
             load_group<LAYOUT, false>(chunk_in, g, nvalid, raw);
-            encode_round<LAYOUT, false, true>(raw, g, nvalid, st, enc, stg, spill, side_chunk,
-                                              nullptr);
+            encode_round<LAYOUT, false, true>(raw, g, nvalid, st, enc, stg, spill, limit,
+                                              side_chunk, nullptr);
         }
     }
     // words asked for but not filled: the zero-padded last word, then an all-zero word
     const uint32_t pending = (uint32_t)(st.nb + (int)st.ab) >> 5;  // 0, 1 or 2 slots
-    put_word(pending > 0, st.p0, (uint32_t)(st.acc << (32 - st.ab)), stg, spill);
-    put_word(pending > 1, st.p1, 0u, stg, spill);
+    put_word(pending > 0, st.p0, (uint32_t)(st.acc << (32 - st.ab)), stg, spill, limit);
+    put_word(pending > 1, st.p1, 0u, stg, spill, limit);
     return st.pos;
 }
 
@@ -334,141 +355,219 @@ template <bool PER_CHUNK>
 struct EncLds {
     uint32_t enc[PER_CHUNK ? kWaves * 256 : 256];
     uint32_t stg[kWaves][kStgWords];
-    u64 base;
-    uint32_t tot[kWaves];
+    u64 base[2];            // exclusive prefix of the tile staged in half h (from the scout)
+    uint32_t tot[2][kWaves];
+    uint32_t base_seq[2];   // (iteration + 1) of the tile base[h] belongs to
     uint32_t ticket;
+    uint32_t done_cnt;      // encoder arrivals, kWaves per iteration, never reset
 };
+
+// Spin on an LDS word until it holds `want` (another wavefront of the workgroup stores it).
+__device__ __forceinline__ void wait_lds_eq(uint32_t* p, const uint32_t want) {
+    while (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != want)
+        __builtin_amdgcn_s_sleep(2);
+}
+__device__ __forceinline__ void wait_lds_ge(uint32_t* p, const uint32_t want) {
+    while (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want)
+        __builtin_amdgcn_s_sleep(2);
+}
 
 // PER_CHUNK = false: one codebook (hf_cb_dev) for the whole stream, its encoder table shared
 // by the workgroup.  PER_CHUNK = true: chunk c is coded with record c of an hf_chunk_cb array
 // (per-block codebooks); each wavefront keeps its chunk's table in its own 1 KiB of LDS.
+//
+// A workgroup is kWaves encoder wavefronts plus one scout.  A tile is kWaves consecutive
+// chunks, one per encoder; tiles are handed out through an atomic ticket, so a tile only ever
+// waits for tiles already running.  The encoder that finishes a tile last publishes the tile's
+// size in its descriptor.  The scout finds the tile's place in the payload (decoupled look-back
+// over the descriptors of the earlier tiles), publishes the inclusive prefix and hands the
+// place to the encoders through LDS; they then copy the staged words out with coalesced stores.
+//
+// When the codebook promises chunks of less than half the staging area (`pipelined`), a
+// wavefront stages two chunks: while tile i is being encoded into one half, the scout places
+// tile i-1, and the encoders copy it out of the other half afterwards.  Waiting for slower
+// workgroups ahead in ticket order and the latency of the descriptor reads then overlap a whole
+// tile of encoding instead of stalling the workgroup.  A chunk that outgrows its half spills to
+// global memory as it would outgrow the whole area.  Otherwise (`lag` = 0) a tile is placed and
+// copied out right after it is encoded.
 template <int LAYOUT, bool PER_CHUNK>
-__global__ __launch_bounds__(kWaves * 64) void hf_k_encode(
-    const void* __restrict__ data, const uint64_t n, const uint32_t nchunks,
-    const void* __restrict__ cbv, uint8_t* __restrict__ side, uint32_t* __restrict__ payload,
-    const uint64_t cap_words, uint32_t* __restrict__ chunk_off, u64* desc, uint32_t* ticket,
-    uint32_t* spill_base, uint32_t* err) {
-    // one object, so that the encoder table sits at LDS address 0 and a lookup's address is the
-    // symbol times four with nothing added
-    __shared__ EncLds<PER_CHUNK> L;
-    uint32_t(&stg_all)[kWaves][kStgWords] = L.stg;
-    uint32_t(&tile_tot)[kWaves] = L.tot;
-    uint32_t& tile_ticket = L.ticket;
-    u64& tile_base = L.base;
-    if (!PER_CHUNK)
-        L.enc[threadIdx.x] = reinterpret_cast<const hf_cb_dev*>(cbv)->enc[threadIdx.x];
-    uint32_t* enc = PER_CHUNK ? L.enc + (threadIdx.x >> 6) * 256 : L.enc;
-
+__global__ __launch_bounds__((kWaves + 1) * 64) __attribute__((amdgpu_waves_per_eu(1, 4))) void
+hf_k_encode(const void* __restrict__ data, const uint64_t n, const uint32_t nchunks,
+            const void* __restrict__ cbv, uint8_t* __restrict__ side,
+            uint32_t* __restrict__ payload, const uint64_t cap_words,
+            uint32_t* __restrict__ chunk_off, u64* desc, uint32_t* ticket, uint32_t* spill_base,
+            uint32_t* err) {
+    // One object, so that the encoder table sits at LDS address 0 and a lookup's address is the
+    // symbol times four with nothing added.  It lives in dynamic LDS on purpose: from a static
+    // size the compiler derives "at most 3 waves per SIMD" and pads the register allocation to
+    // 136 to enforce it, but two 5-wave workgroups per CU put four waves on one SIMD, which
+    // only fit at 128 registers or fewer.
+    extern __shared__ __attribute__((aligned(16))) unsigned char hf_enc_smem[];
+    EncLds<PER_CHUNK>& L = *reinterpret_cast<EncLds<PER_CHUNK>*>(hf_enc_smem);
     const int lane = hf_lane();
-    const int wave = threadIdx.x >> 6;
-    uint32_t* stg = stg_all[wave];
-    uint32_t* spill = spill_base + ((size_t)blockIdx.x * kWaves + wave) * kSpillWords;
+    // (read through readfirstlane so that the compiler knows the value is wave-uniform and the
+    // role split below is a scalar branch)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool scout = wave == kWaves;
+    const int ew = scout ? 0 : wave;  // encoder index (the scout's is never used)
+    uint32_t hint = 0;
+    if (!PER_CHUNK) {
+        const hf_cb_dev* cb = reinterpret_cast<const hf_cb_dev*>(cbv);
+        if (threadIdx.x < 256) L.enc[threadIdx.x] = cb->enc[threadIdx.x];
+        hint = __builtin_amdgcn_readfirstlane(cb->chunk_words_hint);
+    }
+    if (threadIdx.x == 0) {
+        L.base_seq[0] = L.base_seq[1] = 0;
+        L.done_cnt = 0;
+    }
+    const bool pipelined = hint != 0 && hint + kPipeMargin <= (uint32_t)kHalfWords;
+    const uint32_t lag = pipelined ? 1u : 0u;
+    const uint32_t limit = pipelined ? (uint32_t)kHalfWords : (uint32_t)kStgWords;
+    uint32_t* enc = PER_CHUNK ? L.enc + ew * 256 : L.enc;
+    uint32_t* spill_w = spill_base + ((size_t)blockIdx.x * kWaves + ew) * 2 * kSpillWords;
     const size_t elem_bytes = LAYOUT == HF_LAYOUT_BF16_EXP ? 2 : 1;
 
-    // A tile is kWaves consecutive chunks, one per wavefront of the workgroup.  Tiles are handed
-    // out through an atomic ticket, so a tile only ever waits for tiles already running.  The
-    // chunk sizes of a tile are summed through LDS and ONE wavefront runs the look-back for
-    // the tile: with thousands of chunks in flight that keeps the chain of dependent
-    // descriptor reads short.
-    for (;;) {
-        if (threadIdx.x == 0) tile_ticket = atomicAdd(ticket, 1u);
-        __syncthreads();  // (1) ticket visible; also closes the previous tile's LDS reads
-        const uint32_t t = tile_ticket;
-        if ((uint64_t)t * kWaves >= nchunks) break;
-        const uint32_t c = t * kWaves + wave;
+    // state of the tile that is waiting for its place (iteration i - lag)
+    bool pending = false;
+    uint32_t p_t = 0, p_total = 0, p_iter = 0;
+    for (uint32_t i = 0;; ++i) {
+        if (threadIdx.x == 0) L.ticket = atomicAdd(ticket, 1u);
+        __syncthreads();  // ticket visible; the copy-out of the previous iteration is complete
+        const uint32_t t = L.ticket;
+        const bool live = (uint64_t)t * kWaves < nchunks;
+        if (!live && !pending) break;
+        const uint32_t h = i & lag;  // the half tile i is staged in
 
+        // ---- encoders: tile i ----
         uint32_t total = 0;
-        if (c < nchunks) {
-            const uint64_t first = (uint64_t)c * HF_CHUNK_SYMS;
-            const uint64_t left = n - first;
-            const uint32_t nvalid = left < HF_CHUNK_SYMS ? (uint32_t)left : HF_CHUNK_SYMS;
-            const void* chunk_in = reinterpret_cast<const uint8_t*>(data) + first * elem_bytes;
-            uint8_t* side_chunk = side ? side + first : nullptr;
-            if (PER_CHUNK) {
-                const hf_chunk_cb* ccb = reinterpret_cast<const hf_chunk_cb*>(cbv) + c;
+        if (!scout && live) {
+            const uint32_t c = t * kWaves + ew;
+            if (c < nchunks) {
+                const uint64_t first = (uint64_t)c * HF_CHUNK_SYMS;
+                const uint64_t left = n - first;
+                const uint32_t nvalid = left < HF_CHUNK_SYMS ? (uint32_t)left : HF_CHUNK_SYMS;
+                const void* chunk_in = reinterpret_cast<const uint8_t*>(data) + first * elem_bytes;
+                uint8_t* side_chunk = side ? side + first : nullptr;
+                if (PER_CHUNK) {
+                    const hf_chunk_cb* ccb = reinterpret_cast<const hf_chunk_cb*>(cbv) + c;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) enc[lane + 64 * k] = ccb->enc[lane + 64 * k];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    for (int k = 0; k < 4; ++k) enc[lane + 64 * k] = ccb->enc[lane + 64 * k];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+                uint32_t* stg = L.stg[ew] + h * kHalfWords;
+                uint32_t* spill = spill_w + h * kSpillWords;
+                uint32_t buf[kDepth][4];
+                if (nvalid == HF_CHUNK_SYMS) {
+                    preload_chunk<LAYOUT>(chunk_in, lane, buf);
+                    total = encode_chunk<LAYOUT, true>(chunk_in, nvalid, enc, stg, spill, limit,
+                                                       side_chunk, lane, buf);
+                } else {
+                    total = encode_chunk<LAYOUT, false>(chunk_in, nvalid, enc, stg, spill, limit,
+                                                        side_chunk, lane, buf);
+                }
+                total = __builtin_amdgcn_readfirstlane(total);
             }
-            uint32_t buf[kDepth][4];
-            if (nvalid == HF_CHUNK_SYMS) {
-                preload_chunk<LAYOUT>(chunk_in, lane, buf);
-                total = encode_chunk<LAYOUT, true>(chunk_in, nvalid, enc, stg, spill, side_chunk,
-                                                   lane, buf);
+            if (lane == 0) {
+                L.tot[h][ew] = total;
+                // the last encoder to arrive sees every size (the LDS executes one wavefront's
+                // store and atomic in order) and publishes the tile's aggregate
+                const uint32_t arrived = __hip_atomic_fetch_add(
+                    &L.done_cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (arrived == i * kWaves + kWaves - 1) {
+                    uint32_t sum = 0;
+#pragma unroll
+                    for (int w = 0; w < kWaves; ++w) sum += L.tot[h][w];
+                    __hip_atomic_store(&desc[t], kDescAggregate | (u64)sum, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+
+        // ---- the tile to place in this iteration: tile i (lag 0) or tile i-1 (lag 1) ----
+        const bool place = lag ? pending : live;
+        const uint32_t q_t = lag ? p_t : t;
+        const uint32_t q_iter = lag ? p_iter : i;
+        const uint32_t q_total = lag ? p_total : total;
+        const uint32_t qh = q_iter & lag;
+        if (place) {
+            if (scout) {
+                // all sizes of the tile are in LDS once its encoders have all arrived
+                wait_lds_ge(&L.done_cnt, (q_iter + 1) * kWaves);
+                const u64 b = lookback(desc, q_t, lane, err);
+                if (lane == 0) {
+                    uint32_t sum = 0;
+#pragma unroll
+                    for (int w = 0; w < kWaves; ++w) sum += L.tot[qh][w];
+                    __hip_atomic_store(&desc[q_t], kDescPrefix | (b + sum), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                    L.base[qh] = b;
+                    __hip_atomic_store(&L.base_seq[qh], q_iter + 1, __ATOMIC_RELEASE,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             } else {
-                total = encode_chunk<LAYOUT, false>(chunk_in, nvalid, enc, stg, spill, side_chunk,
-                                                    lane, buf);
-            }
-            total = __builtin_amdgcn_readfirstlane(total);
-        }
-        if (lane == 0) tile_tot[wave] = total;
-        __syncthreads();  // (2) all chunk sizes of the tile known; staged words visible
-        uint32_t my_off = 0, tile_total = 0;
+                wait_lds_ge(&L.done_cnt, (q_iter + 1) * kWaves);  // every tot[qh][*] is written
+                wait_lds_eq(&L.base_seq[qh], q_iter + 1);
+                uint32_t my_off = 0;
 #pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-            const uint32_t x = tile_tot[w];
-            my_off += w < wave ? x : 0u;
-            tile_total += x;
-        }
-        if (wave == 0) {
-            if (lane == 0)
-                __hip_atomic_store(&desc[t], kDescAggregate | (u64)tile_total, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            const u64 b = lookback(desc, t, lane, err);
-            if (lane == 0) {
-                __hip_atomic_store(&desc[t], kDescPrefix | (b + tile_total), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-                tile_base = b;
+                for (int w = 0; w < kWaves; ++w) my_off += w < ew ? L.tot[qh][w] : 0u;
+                // the prefix is the same in every lane: keep it in scalar registers so the
+                // branches below are plain scalar branches (the builtin returns int: the halves
+                // pass through uint32_t, or the low one would be sign-extended over the high one
+                // once the payload passes 2^31 words)
+                const u64 tb = L.base[qh];
+                const uint32_t tb_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tb >> 32));
+                const uint32_t tb_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tb);
+                const u64 base = (((u64)tb_hi << 32) | (u64)tb_lo) + my_off;
+                const uint32_t c = q_t * kWaves + ew;
+                if (c < nchunks) {
+                    if (lane == 0) {
+                        chunk_off[c] = (uint32_t)base;
+                        if (c == nchunks - 1) chunk_off[nchunks] = (uint32_t)(base + q_total);
+                    }
+                    const bool fits = base + q_total <= cap_words && base + q_total <= 0xFFFFFFFFull;
+                    if (!fits && lane == 0) atomicOr(err, HF_KERR_OVERFLOW);
+                    const uint32_t ncopy = fits ? q_total : 0u;  // nothing goes past the buffer
+                    const uint32_t in_lds = ncopy < limit ? ncopy : limit;
+                    const uint32_t* stg = L.stg[ew] + qh * kHalfWords;
+                    const uint32_t* spill = spill_w + qh * kSpillWords;
+                    uint32_t* dst = payload + base;
+                    // four LDS reads in flight per lane, then four coalesced 256-byte stores
+                    uint32_t k = lane;
+                    for (; k + 192 < in_lds; k += 256) {
+                        const uint32_t a0 = stg[k], a1 = stg[k + 64], a2 = stg[k + 128],
+                                       a3 = stg[k + 192];
+                        dst[k] = a0;
+                        dst[k + 64] = a1;
+                        dst[k + 128] = a2;
+                        dst[k + 192] = a3;
+                    }
+                    for (; k < in_lds; k += 64) dst[k] = stg[k];
+                    if (ncopy > limit) {
+                        // the spill words were written by other lanes of this wavefront: drain
+                        // the stores, then read them past the vector L1
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        for (uint32_t m = limit + lane; m < ncopy; m += 64)
+                            dst[m] = __hip_atomic_load(&spill[m - limit], __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                }
             }
         }
-        __syncthreads();  // (3) tile base known
-        // the prefix is the same in every lane: keep it in scalar registers so the branches
-        // below are plain scalar branches
-        const u64 tb = tile_base;
-        // (the builtin returns int: the halves pass through uint32_t, or the low one would be
-        // sign-extended over the high one once the payload passes 2^31 words)
-        const uint32_t tb_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tb >> 32));
-        const uint32_t tb_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tb);
-        const u64 base = (((u64)tb_hi << 32) | (u64)tb_lo) + my_off;
-        if (c < nchunks) {
-            if (lane == 0) {
-                chunk_off[c] = (uint32_t)base;
-                if (c == nchunks - 1) chunk_off[nchunks] = (uint32_t)(base + total);
-            }
-            const bool fits = base + total <= cap_words && base + total <= 0xFFFFFFFFull;
-            if (!fits && lane == 0) atomicOr(err, HF_KERR_OVERFLOW);
-            const uint32_t ncopy = fits ? total : 0u;  // nothing is written past the buffer
-            const uint32_t in_lds = ncopy < (uint32_t)kStgWords ? ncopy : (uint32_t)kStgWords;
-            uint32_t* dst = payload + base;
-            // four LDS reads in flight per lane, then four coalesced 256-byte stores
-            uint32_t i = lane;
-            for (; i + 192 < in_lds; i += 256) {
-                const uint32_t a0 = stg[i], a1 = stg[i + 64], a2 = stg[i + 128], a3 = stg[i + 192];
-                dst[i] = a0;
-                dst[i + 64] = a1;
-                dst[i + 128] = a2;
-                dst[i + 192] = a3;
-            }
-            for (; i < in_lds; i += 64) dst[i] = stg[i];
-            if (ncopy > (uint32_t)kStgWords) {
-                // the spill words were written by other lanes of this wavefront: drain the
-                // stores, then read them past the vector L1
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                for (uint32_t k = kStgWords + lane; k < ncopy; k += 64)
-                    dst[k] = __hip_atomic_load(&spill[k - kStgWords], __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-        }
+        pending = lag && live;
+        p_t = t;
+        p_total = total;
+        p_iter = i;
+        if (!live) break;
     }
 }
 
 }  // namespace
 
 size_t hf_encode_spill_bytes(int num_cu) {
-    return (size_t)num_cu * 2 * kWaves * kSpillWords * sizeof(uint32_t);
+    return (size_t)num_cu * 2 * kWaves * 2 * kSpillWords * sizeof(uint32_t);
 }
 
 template <bool PER_CHUNK>
@@ -482,13 +581,24 @@ static void launch_encode_impl(const void* d_data, uint64_t n, int layout, const
     uint64_t grid = (nchunks + kWaves - 1) / kWaves;
     const uint64_t cap = (uint64_t)num_cu * 2;  // two ~70 KiB workgroups fit one CU's LDS
     if (grid > cap) grid = cap;
+    const size_t lds = sizeof(EncLds<PER_CHUNK>);
+    static bool configured = false;  // per instantiation; the calls are idempotent
+    if (!configured) {
+        (void)hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&hf_k_encode<HF_LAYOUT_BF16_EXP, PER_CHUNK>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&hf_k_encode<HF_LAYOUT_U8, PER_CHUNK>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configured = true;
+    }
     if (layout == HF_LAYOUT_BF16_EXP)
         hipLaunchKernelGGL((hf_k_encode<HF_LAYOUT_BF16_EXP, PER_CHUNK>), dim3((unsigned)grid),
-                           dim3(kWaves * 64), 0, s, d_data, n, (uint32_t)nchunks, cb, d_side,
+                           dim3((kWaves + 1) * 64), lds, s, d_data, n, (uint32_t)nchunks, cb, d_side,
                            d_payload, cap_words, d_chunk_off, d_desc, d_ticket, d_spill, d_err);
     else
         hipLaunchKernelGGL((hf_k_encode<HF_LAYOUT_U8, PER_CHUNK>), dim3((unsigned)grid),
-                           dim3(kWaves * 64), 0, s, d_data, n, (uint32_t)nchunks, cb,
+                           dim3((kWaves + 1) * 64), lds, s, d_data, n, (uint32_t)nchunks, cb,
                            (uint8_t*)nullptr, d_payload, cap_words, d_chunk_off, d_desc, d_ticket,
                            d_spill, d_err);
 }
