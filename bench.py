@@ -9,6 +9,7 @@ One step = one pass of the hot path over the whole tensor, inputs resident in HB
 Run as `python bench.py --gpus 1` or under torch.distributed.run with one rank per GPU.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -62,6 +63,36 @@ def cpu_baseline(torch, w_gpu, sample_elems):
         "encode_GBps": gb / (t2 - t0), "decode_GBps": gb / (t3 - t2),
         "seconds": t3 - t0,
     }
+
+
+def pmc_traffic(n):
+    """HBM bytes per launch from the committed rocprofv3 counter passes of this same workload.
+
+    The counters cannot be read from inside this process; tools/profile_bench.sh collects
+    FETCH_SIZE and WRITE_SIZE in separate --pmc runs of this script and writes a summary under
+    profiles/.  FETCH_SIZE is in KiB and counts gfx950's 128-byte requests as 64 bytes, so the
+    read side is doubled; WRITE_SIZE (KiB) is exact.  Returns ({phase: bytes}, file name), or
+    ({}, None) when no summary for `n` elements per GPU is present.
+    """
+    here = os.path.dirname(os.path.abspath(__file__))
+    for path in sorted(glob.glob(os.path.join(here, "profiles", "*_bench_summary.json")),
+                       reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if d.get("elements_per_gpu") != n:
+            continue
+        out = {}
+        for phase, kern in (("hist", "hf_k_hist"), ("encode", "hf_k_encode"),
+                            ("decode", "hf_k_decode")):
+            k = d.get(kern, {})
+            if "FETCH_SIZE_KiB_per_launch" in k and "WRITE_SIZE_KiB_per_launch" in k:
+                out[phase] = (2.0 * k["FETCH_SIZE_KiB_per_launch"]
+                              + k["WRITE_SIZE_KiB_per_launch"]) * 1024.0
+        return out, os.path.join("profiles", os.path.basename(path))
+    return {}, None
 
 
 def main():
@@ -167,11 +198,12 @@ def main():
         "decode": n * (1.0 + lbar / 8.0 + 2.0) + 4.0 * nch,
     }
     roof = {}
+    pmc, pmc_src = pmc_traffic(n)
     for p in ("hist", "encode", "decode"):
         ach = alg[p] / (ms[p] * 1e-3) / 1e9
         roof[p] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                   "frac": ach / HBM_PEAK_GBPS, "traffic": None, "ms": ms[p],
-                   "algorithmic_bytes": alg[p]}
+                   "frac": ach / HBM_PEAK_GBPS, "traffic": pmc.get(p), "ms": ms[p],
+                   "algorithmic_bytes": alg[p], "traffic_source": pmc_src if p in pmc else None}
     dominant = "encode" if ms["encode"] >= ms["decode"] else "decode"
 
     if rank == 0:
