@@ -121,3 +121,45 @@ def test_many_pages_round_trip(hf):
     part = hf.ParrallelHuffmanDecoder().decode_blocks(s, chunk_ids=ids)
     assert torch.equal(part, t.view(n_pages, CH)[ids.long()].reshape(-1))
     assert 1.0 < s.ratio() < 2.0
+
+
+def test_block_codebooks_from_caller_counts(hf, orc):
+    # counts that do not come from a 16384-symbol block: sums of 2^16 and more take the general
+    # 64-bit stages, small ones the per-block fast path; both must agree with the oracle
+    import ctypes as C
+    from huffman_amd import _lib as L
+    rng = np.random.default_rng(21)
+    n_blocks = 70
+    counts = np.zeros((n_blocks, 256), np.uint32)
+    for c in range(n_blocks):
+        kind = c % 5
+        if kind == 0:    # a real block
+            counts[c] = np.bincount(rng.integers(0, 256, CH), minlength=256)
+        elif kind == 1:  # large, smooth
+            counts[c] = rng.integers(1 << 20, 1 << 28, 256)
+        elif kind == 2:  # large with many ties and zeros
+            counts[c] = rng.integers(0, 4, 256) * (1 << 22)
+        elif kind == 3:  # just below / above the fast-path limit
+            counts[c, :8] = [30000, 20000, 10000, 5000, 300, 200, 30 + (c % 2) * 10, 5]
+        else:            # geometric, needs the length limiter
+            counts[c, :40] = (1 << np.arange(40).clip(max=31)).astype(np.uint32)
+    ctx = hf.Context(0)
+    lib = L.lib()
+    d_freq = torch.from_numpy(counts.view(np.int32).reshape(-1)).to(DEV)
+    d_cbs = torch.zeros(n_blocks * L.HF_CHUNK_CODEBOOK_BYTES, dtype=torch.uint8, device=DEV)
+    L.check(lib.hf_system_codebook_chunks_dev(ctx.handle, C.c_void_p(d_freq.data_ptr()), n_blocks,
+                                              hf.HF_MODE_HUFFMAN, 0, C.c_void_p(d_cbs.data_ptr())),
+            "codebooks")
+    code = np.zeros(256, np.uint16)
+    lens = np.zeros(256, np.uint8)
+    mode, ent = C.c_int(0), C.c_uint32(0)
+    for c in range(n_blocks):
+        L.check(lib.hf_chunk_codebook_download(
+            ctx.handle, C.c_void_p(d_cbs.data_ptr()), c,
+            code.ctypes.data_as(C.POINTER(C.c_uint16)), lens.ctypes.data_as(C.POINTER(C.c_uint8)),
+            C.byref(mode), C.byref(ent)), "download")
+        f = counts[c].astype(np.uint64)
+        ecode, elens = orc.rp_system_codebook(f, 64, 0, 16)
+        assert ent.value == orc.rp_entropy_q16_u64(f), c
+        assert np.array_equal(lens, elens), c
+        assert np.array_equal(code, ecode), c
