@@ -42,11 +42,19 @@ struct DecTables {
 struct ChunkTables {
     const uint16_t* lut;     // LDS, HF_LUT_SIZE entries of this wavefront
     const uint8_t* rank2sym; // LDS, 256 entries
+    const uint16_t* tail;    // LDS, direct table over the code space of the 13..16-bit codes
+    uint32_t tail_n;         // entries of `tail` in use; 0: that space is too large, use the blocks
     uint32_t start[4], end[4], off[4];  // lengths 13, 14, 15, 16 (wave-uniform)
 
     __device__ __forceinline__ uint32_t long_code(const uint32_t top, const uint32_t,
                                                   uint32_t& len) const {
         const uint32_t v16 = top >> 16;
+        if (tail_n != 0) {  // wave-uniform: one lookup, as with the stream-wide tables
+            const uint32_t idx = v16 - start[0];
+            const uint32_t e2 = idx < tail_n ? tail[idx] : 0u;
+            len = e2 & 0xFFu;
+            return e2 >> 8;
+        }
         uint32_t p = 0;
         len = 0;
 #pragma unroll
@@ -300,9 +308,11 @@ constexpr int kWavesC = 4;
 // Rebuild one chunk's decode tables from its canonical order.  Lane l holds ranks 4l .. 4l+3.
 // The codes of ranks 0, 1, 2, ... tile the left-aligned 16-bit code space front to back, rank p
 // covering 2^(16 - len_p) values, so a prefix sum of those widths gives every code.
+constexpr int kTailEntries = 1024;  // direct table for the long codes when their space fits
+
 __device__ void build_chunk_tables(const hf_chunk_cb* __restrict__ ccb, uint16_t* __restrict__ lut,
                                    uint8_t* __restrict__ r2s, uint32_t* __restrict__ tmp,
-                                   ChunkTables& T, const int lane) {
+                                   uint16_t* __restrict__ tail, ChunkTables& T, const int lane) {
     const uint32_t lens4 = reinterpret_cast<const uint32_t*>(ccb->len_by_rank)[lane];
     const uint32_t syms4 = reinterpret_cast<const uint32_t*>(ccb->rank2sym)[lane];
     reinterpret_cast<uint32_t*>(r2s)[lane] = syms4;
@@ -340,6 +350,16 @@ __device__ void build_chunk_tables(const hf_chunk_cb* __restrict__ ccb, uint16_t
         cnt_below += c;
         start_acc += c << (16 - d);
     }
+    // Codes of 13..16 bits occupy [start[0], end[3]) of the 16-bit code space; when that is at
+    // most kTailEntries values (rare symbols: the usual case) they get a direct table, so a long
+    // code costs one more lookup instead of the block arithmetic.
+    const uint32_t tail_span = T.end[3] - T.start[0];
+    T.tail_n = tail_span <= (uint32_t)kTailEntries ? tail_span : 0u;
+    if (T.tail_n != 0) {
+#pragma unroll
+        for (int k = 0; k < kTailEntries * 2 / 16 / 64; ++k)
+            reinterpret_cast<uint4*>(tail)[k * 64 + lane] = make_uint4(0, 0, 0, 0);
+    }
     // per-rank fill descriptor for the cooperative phase: first entry | len << 12 | sym << 24
     uint32_t n_wide = 0;  // ranks with span >= 64 (len <= 6); they are the first ranks
 #pragma unroll
@@ -369,12 +389,19 @@ __device__ void build_chunk_tables(const hf_chunk_cb* __restrict__ ccb, uint16_t
             const uint32_t span = 1u << (HF_LUT_BITS - len[i]);
             for (uint32_t k = 0; k < span; ++k) lut[first + k] = val;
         }
+        if (T.tail_n != 0 && len[i] > HF_LUT_BITS && len[i] <= 16) {
+            const uint32_t first = lane_base + start[i] - T.start[0];
+            const uint16_t val = (uint16_t)((((syms4 >> (8 * i)) & 0xFFu) << 8) | len[i]);
+            const uint32_t span = 1u << (16 - len[i]);
+            for (uint32_t k = 0; k < span; ++k) tail[first + k] = val;
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     T.lut = lut;
     T.rank2sym = r2s;
+    T.tail = tail;
 }
 
 template <int LAYOUT>
@@ -388,6 +415,7 @@ __global__ __launch_bounds__(kWavesC * 64) void hf_k_decode_chunks(
     __shared__ __attribute__((aligned(16))) uint32_t stage[kWavesC][kStageWords + kStageSlack];
     __shared__ __attribute__((aligned(16))) uint32_t tmp_all[kWavesC][256];
     __shared__ __attribute__((aligned(16))) uint8_t r2s_all[kWavesC][256];
+    __shared__ __attribute__((aligned(16))) uint16_t tail_all[kWavesC][kTailEntries];
     const int lane = hf_lane();
     const int wv = threadIdx.x >> 6;
     const uint32_t wave = blockIdx.x * kWavesC + wv;
@@ -412,7 +440,7 @@ __global__ __launch_bounds__(kWavesC * 64) void hf_k_decode_chunks(
             continue;
         }
         ChunkTables T;
-        build_chunk_tables(cbs + c, lut_all[wv], r2s_all[wv], tmp_all[wv], T, lane);
+        build_chunk_tables(cbs + c, lut_all[wv], r2s_all[wv], tmp_all[wv], tail_all[wv], T, lane);
         const uint8_t* side_chunk = side ? side + first : nullptr;
         const uint64_t out_first = chunk_ids ? (uint64_t)k * HF_CHUNK_SYMS : first;
         void* out_chunk = reinterpret_cast<uint8_t*>(out) + out_first * elem_bytes;

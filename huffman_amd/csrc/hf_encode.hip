@@ -13,9 +13,11 @@
 //
 // A chunk's words are staged in LDS.  The kWaves chunks a workgroup encodes side by side form a
 // tile; the tile's size is published in a descriptor, a decoupled look-back over the earlier
-// descriptors yields its place in the payload, and the staged words then leave with coalesced
-// stores.  Tiles are handed out through an atomic ticket so a tile only ever waits for tiles
-// whose workgroups are already running.
+// descriptors (run by a fifth, "scout" wavefront of the workgroup) yields its place in the
+// payload, and the staged words then leave with coalesced stores.  Tiles are handed out through
+// an atomic ticket so a tile only ever waits for tiles whose workgroups are already running.
+// With a codebook that promises small chunks a wavefront stages two chunks, and the placement
+// of one tile overlaps the encoding of the next (see hf_k_encode).
 //
 // HBM traffic per bf16 element: 2 B read, 1 B side stream written, ~L/8 B payload written.
 #include <type_traits>
@@ -582,16 +584,16 @@ static void launch_encode_impl(const void* d_data, uint64_t n, int layout, const
     const uint64_t cap = (uint64_t)num_cu * 2;  // two ~70 KiB workgroups fit one CU's LDS
     if (grid > cap) grid = cap;
     const size_t lds = sizeof(EncLds<PER_CHUNK>);
-    static bool configured = false;  // per instantiation; the calls are idempotent
-    if (!configured) {
+    // more than 64 KiB of dynamic LDS has to be allowed per kernel and per device; the call is
+    // idempotent and cheap, so it is simply repeated before every launch
+    if (layout == HF_LAYOUT_BF16_EXP)
         (void)hipFuncSetAttribute(
             reinterpret_cast<const void*>(&hf_k_encode<HF_LAYOUT_BF16_EXP, PER_CHUNK>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    else
         (void)hipFuncSetAttribute(
             reinterpret_cast<const void*>(&hf_k_encode<HF_LAYOUT_U8, PER_CHUNK>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        configured = true;
-    }
     if (layout == HF_LAYOUT_BF16_EXP)
         hipLaunchKernelGGL((hf_k_encode<HF_LAYOUT_BF16_EXP, PER_CHUNK>), dim3((unsigned)grid),
                            dim3((kWaves + 1) * 64), lds, s, d_data, n, (uint32_t)nchunks, cb, d_side,
