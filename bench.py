@@ -55,14 +55,46 @@ def cpu_baseline(torch, w_gpu, sample_elems):
     back = orc.desymbolize(out, side, orc.LAYOUT_BF16_EXP)
     t3 = time.perf_counter()
     assert np.array_equal(back, w)
+    del sym, side, payload, out, back
     gb = 2.0 * m / 1e9
-    return {
+    res = {
         "value": gb / (t3 - t0), "unit": "GB/s", "cores": 1, "kind": "port",
         "sample": f"first {m} bf16 elements of the same tensor ({gb:.2f} GB), "
                   "symbolize+histogram+codebook+encode+decode, single thread, gcc -O3",
         "encode_GBps": gb / (t2 - t0), "decode_GBps": gb / (t3 - t2),
         "seconds": t3 - t0,
     }
+    # the same sample on the host cores this process may use: chunk-aligned shards, one thread
+    # each (the C calls release the interpreter lock), one global codebook
+    from concurrent.futures import ThreadPoolExecutor
+    try:
+        ncore = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncore = os.cpu_count() or 1
+    threads = max(1, min(16, ncore))
+    per = ((m // threads) // 16384 + 1) * 16384
+    bounds = [(lo, min(m, lo + per)) for lo in range(0, m, per)]
+
+    def front(b):
+        s, sd = orc.symbolize(w[b[0]:b[1]], orc.LAYOUT_BF16_EXP)
+        return s, sd, orc.aw_symbol_stat(s, 256, 64)
+
+    def back_half(args):
+        (s, sd, _), b = args
+        p, o = orc.rp_encode(s, code2, lens2)
+        d = orc.rp_decode(p, o, s.size, code2, lens2)
+        return bool(np.array_equal(orc.desymbolize(d, sd, orc.LAYOUT_BF16_EXP), w[b[0]:b[1]]))
+
+    with ThreadPoolExecutor(threads) as ex:
+        u0 = time.perf_counter()
+        parts = list(ex.map(front, bounds))
+        code2, lens2 = orc.rp_system_codebook(sum(p[2] for p in parts), 64, 0, 16)
+        oks = list(ex.map(back_half, zip(parts, bounds)))
+        u1 = time.perf_counter()
+    assert all(oks) and np.array_equal(code2, code) and np.array_equal(lens2, lens)
+    res["all_cores_value"] = gb / (u1 - u0)
+    res["all_cores"] = threads
+    return res
 
 
 def pmc_traffic(n):
