@@ -346,6 +346,58 @@ class EncodedStream:
         raw = self.n * (2 if self.layout == HF_LAYOUT_BF16_EXP else 1)
         return raw / max(1, self.compressed_bytes())
 
+    # -- container (wire format v1, include/huffhip.h) ---------------------------------------------
+    def to_container(self, ctx: Optional["Context"] = None) -> torch.Tensor:
+        """One self-describing uint8 device tensor: header, codebook(s), chunk offsets, side
+        bytes, payload."""
+        assert self.total_words is not None, "encode with sync=True first"
+        ctx = ctx if ctx is not None else default_context()
+        per_chunk = self.chunk_codebooks is not None
+        info = L.hf_container_info()
+        check(L.lib().hf_container_plan(self.n, self.layout, 1 if per_chunk else 0,
+                                        self.total_words, C.byref(info)), "hf_container_plan")
+        blob = torch.empty(int(info.total_bytes), dtype=torch.uint8, device=self.payload.device)
+        cb_ptr = self.chunk_codebooks.data_ptr() if per_chunk else self.codebook.ptr
+        check(L.lib().hf_container_pack(ctx.handle, C.byref(info), C.c_void_p(cb_ptr),
+                                        C.c_void_p(self.chunk_off.data_ptr()),
+                                        C.c_void_p(_dev_ptr(self.side)),
+                                        C.c_void_p(self.payload.data_ptr()),
+                                        C.c_void_p(blob.data_ptr()), blob.numel()),
+              "hf_container_pack")
+        return blob
+
+    @staticmethod
+    def from_container(blob: torch.Tensor, dtype: Optional[torch.dtype] = None,
+                       ctx: Optional["Context"] = None) -> "EncodedStream":
+        """Open a container in device memory.  The stream's payload, offsets and side bytes are
+        views into ``blob`` (nothing is copied); only the codebook tables are rebuilt."""
+        assert blob.dtype == torch.uint8 and blob.is_cuda and blob.is_contiguous()
+        ctx = ctx if ctx is not None else default_context()
+        info = L.hf_container_info()
+        check(L.lib().hf_container_open(ctx.handle, C.c_void_p(blob.data_ptr()), blob.numel(),
+                                        C.byref(info)), "hf_container_open")
+        n, nch, words = int(info.n), int(info.nchunks), int(info.payload_words)
+        per_chunk = info.codebook_kind == L.HF_CODEBOOK_PER_CHUNK
+        if per_chunk:
+            cbs = torch.empty(max(1, nch) * L.HF_CHUNK_CODEBOOK_BYTES, dtype=torch.uint8,
+                              device=blob.device)
+            cb, cb_ptr = None, cbs.data_ptr()
+        else:
+            cbs, cb = None, DeviceCodebook(ctx)
+            cb_ptr = cb.ptr
+        check(L.lib().hf_container_codebook(ctx.handle, C.c_void_p(blob.data_ptr()),
+                                            C.byref(info), C.c_void_p(cb_ptr)),
+              "hf_container_codebook")
+        o_off, o_side, o_pay = int(info.off_chunk_off), int(info.off_side), int(info.off_payload)
+        chunk_off = blob[o_off:o_off + 4 * (nch + 1)].view(torch.int32)
+        side = blob[o_side:o_side + n] if info.layout == HF_LAYOUT_BF16_EXP else None
+        payload = blob[o_pay:int(info.total_bytes)].view(torch.int32)  # padded to >= 4 words
+        if dtype is None:
+            dtype = torch.bfloat16 if info.layout == HF_LAYOUT_BF16_EXP else torch.uint8
+        return EncodedStream(n=n, layout=int(info.layout), dtype=dtype, payload=payload,
+                             chunk_off=chunk_off, side=side, codebook=cb, total_words=words,
+                             chunk_codebooks=cbs)
+
 
 class EntropyAwareHuffmanSystem(_Module):
     """top_encoder.scala:6-184: data_in -> encoded_out, with the bit packer behind it.

@@ -46,6 +46,15 @@ struct hf_chunk_cb {
 };
 static_assert(sizeof(hf_chunk_cb) == HF_CHUNK_CODEBOOK_BYTES, "per-chunk codebook record size");
 
+// Stored form of a per-chunk codebook inside a container (HF_CONTAINER_CHUNK_CODEBOOK_BYTES).
+struct hf_wire_chunk_cb {
+    uint8_t rank2sym[256];  // symbols in (count desc, symbol asc) order
+    uint16_t nlen[16];      // number of ranks with code length 1 .. 16
+    uint32_t mode;
+    uint32_t entropy_q16;
+};
+static_assert(sizeof(hf_wire_chunk_cb) == HF_CONTAINER_CHUNK_CODEBOOK_BYTES, "wire record size");
+
 // Global-memory I/O block of the single-wavefront table stages.
 struct hf_stage_io {
     uint64_t freq[256];
@@ -109,6 +118,10 @@ void hf_launch_decode_chunks(const uint32_t* d_payload, uint64_t payload_words,
                              int layout, const hf_chunk_cb* cbs, const uint32_t* d_chunk_ids,
                              uint64_t n_ids, void* d_out, uint32_t* d_err, int num_cu,
                              hipStream_t s);
+void hf_launch_cb_to_wire(const hf_chunk_cb* cbs, uint64_t nchunks, hf_wire_chunk_cb* out,
+                          hipStream_t s);
+void hf_launch_wire_to_cb(const hf_wire_chunk_cb* in, uint64_t nchunks, hf_chunk_cb* cbs,
+                          uint32_t* d_err, hipStream_t s);
 void hf_launch_decode(const uint32_t* d_payload, uint64_t payload_words,
                       const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n, int layout,
                       const hf_cb_dev* cb, void* d_out, uint32_t* d_err, int num_cu,

@@ -203,6 +203,71 @@ int hf_decode_chunks(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_wo
 int hf_chunk_codebook_download(hf_ctx* ctx, const void* d_chunk_codebooks, uint64_t chunk,
                                uint16_t* h_code, uint8_t* h_len, int* mode, uint32_t* entropy_q16);
 
+/* ---- container: one self-describing blob per encoded stream --------------------------------
+ * The reference stops at one {code, length, mode} beat per symbol (top_encoder.scala:17-21) and
+ * defines no stored form; this is the wire format of this library (version 1, little endian).
+ *
+ *   header, HF_CONTAINER_HEADER_BYTES = 128:
+ *     0 magic "HUFHIP1\0" | 8 u32 version | 12 u32 header_bytes | 16 u32 layout |
+ *     20 u32 codebook_kind | 24 u32 chunk_syms | 28 u32 max_code_len | 32 u32 mode |
+ *     36 u32 entropy_q16 | 40 u64 n | 48 u64 nchunks | 56 u64 payload_words |
+ *     64 u64 off_codebook | 72 u64 off_chunk_off | 80 u64 off_side | 88 u64 off_payload |
+ *     96 u64 total_bytes | 104..127 zero
+ *   sections, each starting on a 16-byte boundary, zero padded, in this order:
+ *     codebook   HF_CODEBOOK_STREAM: code u16[256], length u8[256] (768 bytes);
+ *                HF_CODEBOOK_PER_CHUNK: nchunks records of HF_CONTAINER_CHUNK_CODEBOOK_BYTES:
+ *                rank2sym u8[256] (symbols in (count desc, symbol asc) order), u16[16] number of
+ *                ranks with code length 1..16 (lengths never decrease with rank, codes are
+ *                canonical in rank order), u32 mode, u32 entropy_q16
+ *     chunk_off  u32[nchunks + 1]
+ *     side       u8[n], HF_LAYOUT_BF16_EXP only
+ *     payload    u32[payload_words], padded to at least 16 bytes
+ * Every section can be handed to hf_decode / hf_decode_chunks in place (d_blob + offset), so a
+ * stored stream is decoded, whole or block by block, without unpacking it. */
+#define HF_CONTAINER_VERSION 1
+#define HF_CONTAINER_HEADER_BYTES 128
+#define HF_CONTAINER_CHUNK_CODEBOOK_BYTES 296
+#define HF_CODEBOOK_STREAM 0
+#define HF_CODEBOOK_PER_CHUNK 1
+
+typedef struct hf_container_info {
+    uint32_t version;
+    uint32_t layout;
+    uint32_t codebook_kind;
+    uint32_t chunk_syms;
+    uint32_t max_code_len;
+    uint32_t mode;        /* stream-wide codebook: compression_mode; per chunk: in the records */
+    uint32_t entropy_q16; /* stream-wide codebook only */
+    uint32_t reserved;
+    uint64_t n;
+    uint64_t nchunks;
+    uint64_t payload_words;
+    uint64_t off_codebook;
+    uint64_t off_chunk_off;
+    uint64_t off_side; /* 0 when there is no side stream */
+    uint64_t off_payload;
+    uint64_t total_bytes;
+} hf_container_info;
+
+/* Section offsets and the total size for a stream of n symbols (host arithmetic only). */
+int hf_container_plan(uint64_t n, int layout, int codebook_kind, uint64_t payload_words,
+                      hf_container_info* info);
+/* Write the blob: header from `info` (as filled by hf_container_plan; mode / entropy are taken
+ * from the device codebook), codebook(s) in wire form, offsets, side bytes, payload.  All
+ * pointers are device pointers; d_codebook is an HF_CODEBOOK_DEV_BYTES codebook or an array of
+ * HF_CHUNK_CODEBOOK_BYTES records according to info->codebook_kind.  Synchronises. */
+int hf_container_pack(hf_ctx* ctx, hf_container_info* info, const void* d_codebook,
+                      const uint32_t* d_chunk_off, const uint8_t* d_side,
+                      const uint32_t* d_payload, void* d_blob, uint64_t blob_cap_bytes);
+/* Read and validate the header of a blob in device memory (HF_ERR_CORRUPT if it is not a
+ * version-1 container that fits blob_bytes).  Synchronises. */
+int hf_container_open(hf_ctx* ctx, const void* d_blob, uint64_t blob_bytes,
+                      hf_container_info* info);
+/* Rebuild the device codebook(s) of an opened blob into d_codebook_out (HF_CODEBOOK_DEV_BYTES,
+ * or nchunks * HF_CHUNK_CODEBOOK_BYTES for per-chunk codebooks).  Synchronises. */
+int hf_container_codebook(hf_ctx* ctx, const void* d_blob, const hf_container_info* info,
+                          void* d_codebook_out);
+
 /* ---- TreeQualityAnalyzer (tree_q_analyser.scala:10-47) ------------------------------------- */
 int hf_quality(hf_ctx* ctx, const uint64_t* h_freq, const uint8_t* h_len, int N, int wt_width,
                uint16_t* avg_len_q8, uint16_t* efficiency, uint16_t* compression_ratio);

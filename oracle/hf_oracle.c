@@ -560,3 +560,91 @@ int orc_rp_decode(const uint32_t* payload, const uint32_t* chunk_off, size_t n,
     free(tab);
     return rc;
 }
+
+/* ---- container, wire format version 1 ------------------------------------------------------- */
+static uint64_t round16(uint64_t x) { return (x + 15u) / 16u * 16u; }
+
+static void le32(uint8_t* p, uint32_t v) {
+    for (int i = 0; i < 4; ++i) p[i] = (uint8_t)(v >> (8 * i));
+}
+static void le64(uint8_t* p, uint64_t v) {
+    for (int i = 0; i < 8; ++i) p[i] = (uint8_t)(v >> (8 * i));
+}
+
+/* offsets of the four sections and the total size */
+static void container_offsets(uint64_t n, int layout, int kind, uint64_t payload_words,
+                              uint64_t off[4], uint64_t* total) {
+    const uint64_t nchunks = orc_num_chunks((size_t)n);
+    uint64_t at = 128;
+    off[0] = at;
+    at = round16(at + (kind == 0 ? 768u : nchunks * 296u));
+    off[1] = at;
+    at = round16(at + 4u * (nchunks + 1));
+    off[2] = 0;
+    if (layout == ORC_LAYOUT_BF16_EXP) {
+        off[2] = at;
+        at = round16(at + n);
+    }
+    off[3] = at;
+    at += payload_words * 4u < 16u ? 16u : round16(payload_words * 4u);
+    *total = at;
+}
+
+uint64_t orc_container_bytes(uint64_t n, int layout, int kind, uint64_t payload_words) {
+    uint64_t off[4], total;
+    container_offsets(n, layout, kind, payload_words, off, &total);
+    return total;
+}
+
+uint64_t orc_container_pack(uint8_t* out, uint64_t n, int layout, int kind, uint64_t payload_words,
+                            uint32_t mode, uint32_t entropy_q16, const uint16_t* code,
+                            const uint8_t* len, const uint8_t* rank2sym,
+                            const uint8_t* len_by_rank, const uint32_t* modes,
+                            const uint32_t* entropies, const uint32_t* chunk_off,
+                            const uint8_t* side, const uint32_t* payload) {
+    uint64_t off[4], total;
+    container_offsets(n, layout, kind, payload_words, off, &total);
+    const uint64_t nchunks = orc_num_chunks((size_t)n);
+    memset(out, 0, (size_t)total);
+    memcpy(out, "HUFHIP1", 8);
+    le32(out + 8, 1);
+    le32(out + 12, 128);
+    le32(out + 16, (uint32_t)layout);
+    le32(out + 20, (uint32_t)kind);
+    le32(out + 24, ORC_CHUNK_SYMS);
+    le32(out + 28, 16);
+    le32(out + 32, kind == 0 ? mode : 0xFFFFFFFFu);
+    le32(out + 36, kind == 0 ? entropy_q16 : 0u);
+    le64(out + 40, n);
+    le64(out + 48, nchunks);
+    le64(out + 56, payload_words);
+    for (int i = 0; i < 4; ++i) le64(out + 64 + 8 * i, off[i]);
+    le64(out + 96, total);
+    uint8_t* p = out + off[0];
+    if (kind == 0) {
+        for (int s = 0; s < 256; ++s) {
+            p[2 * s] = (uint8_t)(code[s] & 0xFF);
+            p[2 * s + 1] = (uint8_t)(code[s] >> 8);
+            p[512 + s] = len[s];
+        }
+    } else {
+        for (uint64_t c = 0; c < nchunks; ++c, p += 296) {
+            uint32_t per_len[17] = {0};
+            memcpy(p, rank2sym + c * 256, 256);
+            for (int r = 0; r < 256; ++r) {
+                const unsigned l = len_by_rank[c * 256 + r];
+                if (l >= 1 && l <= 16) per_len[l]++;
+            }
+            for (int l = 1; l <= 16; ++l) {
+                p[256 + 2 * (l - 1)] = (uint8_t)(per_len[l] & 0xFF);
+                p[256 + 2 * (l - 1) + 1] = (uint8_t)(per_len[l] >> 8);
+            }
+            le32(p + 288, modes[c]);
+            le32(p + 292, entropies[c]);
+        }
+    }
+    for (uint64_t c = 0; c <= nchunks; ++c) le32(out + off[1] + 4 * c, chunk_off[c]);
+    if (off[2] && n) memcpy(out + off[2], side, (size_t)n);
+    for (uint64_t w = 0; w < payload_words; ++w) le32(out + off[3] + 4 * w, payload[w]);
+    return total;
+}

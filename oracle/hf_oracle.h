@@ -138,6 +138,25 @@ size_t orc_num_chunks(size_t n);
 /* Upper bound on payload words for n symbols under any codebook with lengths <= 16. */
 uint64_t orc_payload_bound_words(size_t n);
 
+/* Container, wire format version 1 (the reference defines no stored form, top_encoder.scala:17-21
+ * ends at the {code, length, mode} beat; the format is this build's): a 128-byte little-endian
+ * header (magic "HUFHIP1\0", version, header size, layout, codebook kind, chunk symbols, maximum
+ * code length, mode, entropy, n, nchunks, payload words, four section offsets, total size), then
+ * the codebook section, chunk offsets, side bytes (bf16 exponent layout only) and payload, each
+ * starting on a 16-byte boundary and zero padded; the payload section holds at least 16 bytes.
+ * kind 0: one codebook, code u16[256] + length u8[256].  kind 1: one 296-byte record per chunk:
+ * rank2sym u8[256], u16[16] number of ranks per code length 1..16, u32 mode, u32 entropy. */
+uint64_t orc_container_bytes(uint64_t n, int layout, int kind, uint64_t payload_words);
+/* Writes the container into out (orc_container_bytes() bytes) and returns its size.  kind 0 uses
+ * mode, entropy_q16, code, len; kind 1 uses rank2sym, len_by_rank (nchunks x 256 each), modes,
+ * entropies (nchunks each). */
+uint64_t orc_container_pack(uint8_t* out, uint64_t n, int layout, int kind, uint64_t payload_words,
+                            uint32_t mode, uint32_t entropy_q16, const uint16_t* code,
+                            const uint8_t* len, const uint8_t* rank2sym,
+                            const uint8_t* len_by_rank, const uint32_t* modes,
+                            const uint32_t* entropies, const uint32_t* chunk_off,
+                            const uint8_t* side, const uint32_t* payload);
+
 #ifdef __cplusplus
 }
 #endif
