@@ -20,7 +20,7 @@ HF_ERR_OVERFLOW, HF_ERR_TIMEOUT, HF_ERR_CORRUPT, HF_ERR_NOMEM = -5, -6, -7, -8
 HF_LAYOUT_U8, HF_LAYOUT_BF16_EXP, HF_LAYOUT_FP8 = 0, 1, 2
 HF_CHUNK_SYMS = 16384
 HF_MAX_CODE_LEN = 16
-HF_MODE_BYPASS, HF_MODE_HUFFMAN, HF_MODE_AUTO = 0, 1, 2
+HF_MODE_BYPASS, HF_MODE_HUFFMAN, HF_MODE_AUTO, HF_MODE_BEST = 0, 1, 2, 3
 HF_CODEBOOK_DEV_BYTES = 20480
 HF_CHUNK_CODEBOOK_BYTES = 1552
 HF_CONTAINER_VERSION = 1

@@ -17,7 +17,7 @@ import torch
 
 from . import _lib as L
 from ._lib import (HF_CHUNK_SYMS, HF_CODEBOOK_DEV_BYTES, HF_LAYOUT_BF16_EXP, HF_LAYOUT_FP8,
-                   HF_LAYOUT_U8, HF_MODE_AUTO, HF_MODE_BYPASS, HF_MODE_HUFFMAN, HuffhipError,
+                   HF_LAYOUT_U8, HF_MODE_AUTO, HF_MODE_BEST, HF_MODE_BYPASS, HF_MODE_HUFFMAN, HuffhipError,
                    check, hf_entropy_config)
 
 _u8p, _u16p, _u32p, _u64p = (C.POINTER(C.c_uint8), C.POINTER(C.c_uint16), C.POINTER(C.c_uint32),

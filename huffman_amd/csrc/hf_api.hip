@@ -334,7 +334,9 @@ int hf_codebook(hf_ctx* ctx, const uint64_t* h_freq, int N, const hf_entropy_con
 int hf_system_codebook_dev(hf_ctx* ctx, const uint64_t* d_freq256, int mode,
                            uint64_t min_freq_threshold, void* d_codebook) {
     if (!ctx || !d_freq256 || !d_codebook) return HF_ERR_ARG;
-    if (mode != HF_MODE_BYPASS && mode != HF_MODE_HUFFMAN && mode != HF_MODE_AUTO) return HF_ERR_ARG;
+    if (mode != HF_MODE_BYPASS && mode != HF_MODE_HUFFMAN && mode != HF_MODE_AUTO &&
+        mode != HF_MODE_BEST)
+        return HF_ERR_ARG;
     if (!aligned16(d_freq256) || !aligned16(d_codebook)) return HF_ERR_ALIGN;
     if (int rc = use_device(ctx)) return rc;
     hf_cb_dev* cb = reinterpret_cast<hf_cb_dev*>(d_codebook);
@@ -484,7 +486,9 @@ int hf_symbol_stat_chunks_dev(hf_ctx* ctx, const void* d_data, uint64_t n, int l
 int hf_system_codebook_chunks_dev(hf_ctx* ctx, const uint32_t* d_freq_chunks, uint64_t nchunks,
                                   int mode, uint64_t min_freq_threshold, void* d_chunk_codebooks) {
     if (!ctx || (nchunks && (!d_freq_chunks || !d_chunk_codebooks))) return HF_ERR_ARG;
-    if (mode != HF_MODE_BYPASS && mode != HF_MODE_HUFFMAN && mode != HF_MODE_AUTO) return HF_ERR_ARG;
+    if (mode != HF_MODE_BYPASS && mode != HF_MODE_HUFFMAN && mode != HF_MODE_AUTO &&
+        mode != HF_MODE_BEST)
+        return HF_ERR_ARG;
     if (!aligned16(d_freq_chunks) || !aligned16(d_chunk_codebooks)) return HF_ERR_ALIGN;
     if (nchunks > 0x7FFFFFFFull) return HF_ERR_RANGE;
     if (int rc = use_device(ctx)) return rc;

@@ -370,16 +370,13 @@ __global__ __launch_bounds__(64) void hf_k_system(const u64* __restrict__ freq25
     stage_sort(freq256, N, sorted, L.rank2sym, lane);
     const uint32_t ent = stage_entropy(freq256, N, lane);
     const uint32_t emode = entropy_mode(ent);
-    const uint32_t mode = mode_req == HF_MODE_AUTO ? emode : (uint32_t)(mode_req & 1);
+    // HF_MODE_BEST builds the Huffman tables first and keeps them only if they pay
+    uint32_t mode = mode_req == HF_MODE_BEST   ? (uint32_t)HF_MODE_HUFFMAN
+                    : mode_req == HF_MODE_AUTO ? emode
+                                               : (uint32_t)(mode_req & 1);
     __syncthreads();
-    if (mode == HF_MODE_BYPASS) {
-        // bypass table, top_encoder.scala:131-137: code(i) = i, length = symWidth
-        for (int s = lane; s < 256; s += 64) {
-            cb->enc[s] = (uint32_t)s | (8u << 16);
-            cb->code[s] = (uint16_t)s;
-            cb->len[s] = 8;
-        }
-    } else {
+    u64 bits = 0, cnt = 0;
+    if (mode == HF_MODE_HUFFMAN) {
         for (int e = lane; e < N; e += 64) {
             const u64 f = sorted[e];
             L.w[e] = f < thr ? 0ull : f;
@@ -389,26 +386,36 @@ __global__ __launch_bounds__(64) void hf_k_system(const u64* __restrict__ freq25
         stage_adjust(L, N, HF_MAX_CODE_LEN, lane);
         stage_canonical(L, N, lane);
         for (int p = lane; p < N; p += 64) {
+            const u64 f = sorted[p];
+            bits += f * (u64)L.adj[p];
+            cnt += f;
+        }
+        bits = hf_wave_sum_u64(bits);
+        cnt = hf_wave_sum_u64(cnt);
+        if (mode_req == HF_MODE_BEST && bits >= 8ull * cnt) mode = HF_MODE_BYPASS;
+    }
+    if (mode == HF_MODE_BYPASS) {
+        // bypass table, top_encoder.scala:131-137: code(i) = i, length = symWidth
+        for (int s = lane; s < 256; s += 64) {
+            cb->enc[s] = (uint32_t)s | (8u << 16);
+            cb->code[s] = (uint16_t)s;
+            cb->len[s] = 8;
+        }
+        bits = 8, cnt = 1;
+    } else {
+        for (int p = lane; p < N; p += 64) {
             const int s = L.rank2sym[p];
             cb->enc[s] = (uint32_t)L.code[p] | ((uint32_t)L.adj[p] << 16);
             cb->code[s] = L.code[p];
             cb->len[s] = (uint8_t)L.adj[p];
         }
     }
-    // expected payload of a full chunk: 16384 symbols x mean code length, in 32-bit words, plus
-    // the two look-ahead words each of the 64 lanes may leave behind
-    u64 bits = 0, cnt = 0;
-    for (int p = lane; p < N; p += 64) {
-        const u64 f = sorted[p];
-        bits += f * (mode == HF_MODE_BYPASS ? 8ull : (u64)L.adj[p]);
-        cnt += f;
-    }
-    bits = hf_wave_sum_u64(bits);
-    cnt = hf_wave_sum_u64(cnt);
     if (lane == 0) {
         cb->mode = mode;
         cb->entropy_q16 = ent;
         cb->entropy_mode = emode;
+        // expected payload of a full chunk: 16384 symbols x mean code length, in 32-bit words,
+        // plus the two look-ahead words each of the 64 lanes may leave behind
         cb->chunk_words_hint = cnt ? (uint32_t)(bits * (HF_CHUNK_SYMS / 32) / cnt) + 128u : 0u;
     }
 }
@@ -488,17 +495,22 @@ __device__ void chunk_codebook_fast(CbLdsSmall& L, const uint32_t (&cnt_by_sym)[
     acc = hf_wave_sum_u32(acc);
     const uint32_t ent = 0x10000u - acc;
     const uint32_t emode = entropy_mode(ent);
-    const uint32_t mode = mode_req == HF_MODE_AUTO ? emode : (uint32_t)(mode_req & 1);
-    if (lane == 0) {
-        cb->mode = mode;
-        cb->entropy_q16 = ent;
-    }
-    if (mode == HF_MODE_BYPASS) {
+    uint32_t mode = mode_req == HF_MODE_BEST   ? (uint32_t)HF_MODE_HUFFMAN
+                    : mode_req == HF_MODE_AUTO ? emode
+                                               : (uint32_t)(mode_req & 1);
+    auto write_bypass = [&]() {
         for (int s = lane; s < 256; s += 64) {
             cb->enc[s] = (uint32_t)s | (8u << 16);
             cb->rank2sym[s] = (uint8_t)s;
             cb->len_by_rank[s] = 8;
         }
+        if (lane == 0) {
+            cb->mode = HF_MODE_BYPASS;
+            cb->entropy_q16 = ent;
+        }
+    };
+    if (mode == HF_MODE_BYPASS) {
+        write_bypass();
         return;
     }
     // ---- sFilter (entropy_aware_tree_builder.scala:61-66) ----
@@ -618,6 +630,21 @@ __device__ void chunk_codebook_fast(CbLdsSmall& L, const uint32_t (&cnt_by_sym)[
     __syncthreads();
     stage_adjust(L, N, HF_MAX_CODE_LEN, lane);
     stage_canonical(L, N, lane);
+    if (mode_req == HF_MODE_BEST) {
+        // keep the Huffman table only if it saves bits on this block's own counts
+        uint32_t bits = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bits += f[i] * (uint32_t)L.adj[lane * 4 + i];
+        bits = hf_wave_sum_u32(bits);
+        if (bits >= 8u * tot) {
+            write_bypass();
+            return;
+        }
+    }
+    if (lane == 0) {
+        cb->mode = HF_MODE_HUFFMAN;
+        cb->entropy_q16 = ent;
+    }
     // ---- outputs: encoder table by symbol, canonical order packed four ranks per store ----
     uint32_t r2s4 = 0, len4 = 0;
 #pragma unroll
@@ -683,15 +710,11 @@ __global__ __launch_bounds__(64) void hf_k_system_chunks_rest(
             stage_sort(fq, N, sorted, L.rank2sym, lane);
             const uint32_t ent = stage_entropy(fq, N, lane);
             const uint32_t emode = entropy_mode(ent);
-            const uint32_t mode = mode_req == HF_MODE_AUTO ? emode : (uint32_t)(mode_req & 1);
+            uint32_t mode = mode_req == HF_MODE_BEST   ? (uint32_t)HF_MODE_HUFFMAN
+                            : mode_req == HF_MODE_AUTO ? emode
+                                                       : (uint32_t)(mode_req & 1);
             __syncthreads();
-            if (mode == HF_MODE_BYPASS) {
-                for (int s = lane; s < 256; s += 64) {
-                    cb->enc[s] = (uint32_t)s | (8u << 16);
-                    cb->rank2sym[s] = (uint8_t)s;
-                    cb->len_by_rank[s] = 8;
-                }
-            } else {
+            if (mode == HF_MODE_HUFFMAN) {
                 for (int e = lane; e < N; e += 64) {
                     const u64 f = sorted[e];
                     L.w[e] = f < thr ? 0ull : f;
@@ -700,6 +723,24 @@ __global__ __launch_bounds__(64) void hf_k_system_chunks_rest(
                 stage_tree(L, N, lane);
                 stage_adjust(L, N, HF_MAX_CODE_LEN, lane);
                 stage_canonical(L, N, lane);
+                if (mode_req == HF_MODE_BEST) {
+                    u64 bits = 0, cnt = 0;
+                    for (int p = lane; p < N; p += 64) {
+                        bits += sorted[p] * (u64)L.adj[p];
+                        cnt += sorted[p];
+                    }
+                    bits = hf_wave_sum_u64(bits);
+                    cnt = hf_wave_sum_u64(cnt);
+                    if (bits >= 8ull * cnt) mode = HF_MODE_BYPASS;
+                }
+            }
+            if (mode == HF_MODE_BYPASS) {
+                for (int s = lane; s < 256; s += 64) {
+                    cb->enc[s] = (uint32_t)s | (8u << 16);
+                    cb->rank2sym[s] = (uint8_t)s;
+                    cb->len_by_rank[s] = 8;
+                }
+            } else {
                 for (int p = lane; p < N; p += 64) {
                     const int s = L.rank2sym[p];
                     cb->enc[s] = (uint32_t)L.code[p] | ((uint32_t)L.adj[p] << 16);

@@ -51,6 +51,10 @@ extern "C" {
 #define HF_MODE_BYPASS 0
 #define HF_MODE_HUFFMAN 1
 #define HF_MODE_AUTO 2 /* let the entropy decision choose (system calls only) */
+#define HF_MODE_BEST 3 /* build the Huffman table, keep it only if sum(count x length) is below
+                          8 bits per symbol on the counts it was built from, else bypass (system
+                          calls only; the as-written entropy decision of HF_MODE_AUTO is no
+                          measure of compressibility, see shannon_entropy.scala:78-91) */
 
 typedef struct hf_ctx hf_ctx;
 

@@ -648,3 +648,12 @@ uint64_t orc_container_pack(uint8_t* out, uint64_t n, int layout, int kind, uint
     for (uint64_t w = 0; w < payload_words; ++w) le32(out + off[3] + 4 * w, payload[w]);
     return total;
 }
+
+int orc_rp_best_mode(const uint64_t* freq_by_symbol, const uint8_t* len_by_symbol, int N) {
+    unsigned __int128 bits = 0, total = 0;
+    for (int s = 0; s < N; ++s) {
+        bits += (unsigned __int128)freq_by_symbol[s] * len_by_symbol[s];
+        total += freq_by_symbol[s];
+    }
+    return bits < 8 * total ? 1 : 0;
+}

@@ -138,6 +138,11 @@ size_t orc_num_chunks(size_t n);
 /* Upper bound on payload words for n symbols under any codebook with lengths <= 16. */
 uint64_t orc_payload_bound_words(size_t n);
 
+/* Mode choice "best": 1 (Huffman) if the table saves bits on the counts it was built from,
+ * sum(freq x len) < 8 x sum(freq), else 0 (bypass).  Not in the reference, whose entropy
+ * decision (shannon_entropy.scala:78-91) is no measure of compressibility. */
+int orc_rp_best_mode(const uint64_t* freq_by_symbol, const uint8_t* len_by_symbol, int N);
+
 /* Container, wire format version 1 (the reference defines no stored form, top_encoder.scala:17-21
  * ends at the {code, length, mode} beat; the format is this build's): a 128-byte little-endian
  * header (magic "HUFHIP1\0", version, header size, layout, codebook kind, chunk symbols, maximum

@@ -299,6 +299,15 @@ def container_pack(n, layout, payload, chunk_off, side=None, code=None, lens=Non
     return out
 
 
+def rp_best_mode(freq, lens) -> int:
+    freq = _arr(freq, np.uint64)
+    lens = _arr(lens, np.uint8)
+    l = lib()
+    l.orc_rp_best_mode.argtypes = [_u64p, _u8p, C.c_int]
+    l.orc_rp_best_mode.restype = C.c_int
+    return int(l.orc_rp_best_mode(_p(freq, _u64p), _p(lens, _u8p), freq.size))
+
+
 def payload_bound_words(n: int) -> int:
     return int(lib().orc_payload_bound_words(n))
 

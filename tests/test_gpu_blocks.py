@@ -163,3 +163,47 @@ def test_block_codebooks_from_caller_counts(hf, orc):
         assert ent.value == orc.rp_entropy_q16_u64(f), c
         assert np.array_equal(lens, elens), c
         assert np.array_equal(code, ecode), c
+
+
+def test_best_mode_keeps_huffman_only_where_it_pays(hf, orc):
+    # blocks of uniform bytes (Huffman cannot win: bypass), skewed blocks (Huffman), an empty-ish
+    # tail; the stream-wide codebook follows the same rule on the whole stream
+    rng = np.random.default_rng(41)
+    blocks = []
+    for c in range(24):
+        if c % 3 == 0:
+            blocks.append(np.arange(CH, dtype=np.uint8))             # exactly uniform: 8.0 bits
+        elif c % 3 == 1:
+            blocks.append(rng.integers(0, 256, CH, dtype=np.uint8))  # ~7.99 bits: Huffman may win
+        else:
+            blocks.append(np.minimum(rng.geometric(0.2, CH) - 1, 255).astype(np.uint8))
+    sym = np.concatenate(blocks + [np.full(100, 9, np.uint8)])
+    t = torch.from_numpy(sym).to(DEV)
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    s = sys_.encode_blocks(t, mode=hf.HF_MODE_BEST)
+    seen = set()
+    for c in range(25):
+        blk = sym[c * CH:(c + 1) * CH]
+        f = orc.aw_symbol_stat(blk, 256, 32)
+        ecode, elens = orc.rp_system_codebook(f, 64, 0, 16)
+        emode = orc.rp_best_mode(f, elens)
+        code, lens, mode, ent = sys_.block_codebook(s, c)
+        assert mode == emode, c
+        seen.add(mode)
+        if mode == 1:
+            assert np.array_equal(code, ecode) and np.array_equal(lens, elens)
+        else:
+            assert np.array_equal(code, np.arange(256)) and np.all(lens == 8)
+    assert seen == {0, 1}
+    assert torch.equal(hf.ParrallelHuffmanDecoder().decode(s), t)
+    # stream-wide
+    for data in (np.arange(1 << 16, dtype=np.uint8), sym):
+        d = torch.from_numpy(data).to(DEV)
+        st = sys_.encode(d, mode=hf.HF_MODE_BEST)
+        f = orc.aw_symbol_stat(data, 256, 64)
+        ecode, elens = orc.rp_system_codebook(f, 64, 0, 16)
+        code, lens, mode, _ = st.codebook.download()
+        assert mode == orc.rp_best_mode(f, elens)
+        if mode == 1:
+            assert np.array_equal(code, ecode) and np.array_equal(lens, elens)
+        assert torch.equal(hf.ParrallelHuffmanDecoder().decode(st), d)
