@@ -151,9 +151,16 @@ def main():
         raise SystemExit("for --gpus N > 1 launch with torch.distributed.run, one rank per GPU")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # HF_BENCH_FORCE_DIST=1 takes the multi-rank code path (process group, all-reduce, barriers)
+    # with a single rank, to rehearse it on a one-GPU box
+    use_dist = world > 1 or os.environ.get("HF_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if world == 1:
+            dist.init_process_group("nccl", device_id=device, rank=0, world_size=1)
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     n = args.elems
     w = make_weights(torch, n, device)
@@ -175,7 +182,7 @@ def main():
         freq.zero_()
         stat.accumulate(w, freq)
         if ev: ev[1].record()
-        if world > 1:
+        if use_dist:
             dist.all_reduce(freq)  # global codebook: identical tables on every rank
         system.codebook(freq, hf.HF_MODE_HUFFMAN, out=cb)
         if ev: ev[2].record()
@@ -188,7 +195,7 @@ def main():
     for _ in range(args.warmup):
         s = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
 
@@ -197,11 +204,11 @@ def main():
     for k in range(args.steps):
         s = step(evs[k])
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -272,7 +279,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(torch, w, args.cpu_sample)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if not ok:
