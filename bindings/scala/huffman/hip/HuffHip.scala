@@ -1,18 +1,10 @@
-# INTEGRATION — using libhuffhip from the reference's side
-
-`libhuffhip.so` (built by `make -C huffman_amd/csrc`, gfx950 only) exports a plain C ABI
-(`include/huffhip.h`): opaque `hf_ctx*`, pointers and sizes, integer error codes. Bulk data are
-device pointers (16-byte aligned), tables of a few KiB are host pointers. There is no CPU
-fallback inside the library.
-
-## Scala (the reference's language) over JNA
-
-The reference has no FFI today; a maintainer would add one interface next to
-`src/main/scala/huffman/` and keep the Chisel class names for the software path. No JVM exists
-in the build image, so this is source only and has not been compiled; the same text, with more
-module twins, is kept as a file in `bindings/scala/huffman/hip/HuffHip.scala`.
-
-```scala
+// JNA binding of libhuffhip.so (include/huffhip.h) with software twins of the reference's Chisel
+// modules: same class names, same constructor parameters, functions instead of ports.
+//
+// SOURCE ONLY: the image this library is built in has no JVM, sbt or JNA jar, so this file has
+// never been compiled.  It needs net.java.dev.jna:jna (5.x) on the class path and
+// libhuffhip.so on jna.library.path.  Device buffers are raw device addresses wrapped in
+// com.sun.jna.Pointer (from any HIP binding the JVM side already uses).
 package huffman.hip
 
 import com.sun.jna.{Library, Native, Pointer, Structure}
@@ -113,82 +105,50 @@ class SymbolStat(val sym_width: Int, val wtWidth: Int, val depth: Int)(implicit 
     require(rc == 0, s"hf_symbol_stat: $rc"); f
   }
 }
-```
 
-Device buffers come from any HIP allocator the JVM side already uses (a HIP JNA binding,
-or tensors handed over by a DL runtime); the library only needs raw device addresses.
-With Project Panama the same header feeds `jextract -l huffhip include/huffhip.h`.
+/** Software twin of SymbolSort (symbol_sort.scala:82-148): sorted counts and the rank -> symbol map. */
+class SymbolSort(val depth: Int, val wtWidth: Int)(implicit ctx: Pointer) {
+  def apply(freq: Array[Long]): (Array[Long], Array[Short]) = {
+    val sorted = new Array[Long](depth); val rank2sym = new Array[Short](depth)
+    val rc = HuffHip.lib.hf_symbol_sort(ctx, freq, depth, sorted, rank2sym)
+    require(rc == 0, s"hf_symbol_sort: $rc"); (sorted, rank2sym)
+  }
+}
 
-## Python (what the tests use)
+/** Software twin of EntropyAwareTreeBuilder (entropy_aware_tree_builder.scala:6-169). */
+class EntropyAwareTreeBuilder(val depth: Int, val wtWidth: Int)(implicit ctx: Pointer) {
+  def apply(freq: Array[Long], minFreqThreshold: Long = 0L): (Array[Short], Array[Byte]) = {
+    val cfg = new EntropyConfig; cfg.min_freq_threshold = minFreqThreshold
+    val code = new Array[Short](depth); val len = new Array[Byte](depth)
+    val rc = HuffHip.lib.hf_codebook(ctx, freq, depth, cfg, code, len)
+    require(rc == 0, s"hf_codebook: $rc"); (code, len)
+  }
+}
 
-`huffman_amd/api.py` is the ctypes mirror with the Chisel class names; `huffman_amd/_lib.py`
-holds one signature per exported symbol (checked against the header by `tests/test_abi.py`).
+/** Software twin of EntropyAwareHuffmanSystem (top_encoder.scala:6-184) with the bit packer:
+  * device tensor in, packed stream (payload, chunk offsets, side bytes) out. */
+class EntropyAwareHuffmanSystem(val symWidth: Int = 8, val wtWidth: Int = 32, val depth: Int = 256,
+                                val maxCodeLen: Int = 16)(implicit ctx: Pointer) {
+  /** dFreq256: zeroed uint64[256]; dCodebook: HF_CODEBOOK_DEV_BYTES; returns the payload words. */
+  def encode(dData: Pointer, n: Long, layout: Int, mode: Int, dFreq256: Pointer, dCodebook: Pointer,
+             dSide: Pointer, dPayload: Pointer, payloadCapWords: Long, dChunkOff: Pointer): Long = {
+    val lib = HuffHip.lib
+    require(lib.hf_symbol_stat_dev(ctx, dData, n, layout, dFreq256) == 0)
+    require(lib.hf_system_codebook_dev(ctx, dFreq256, mode, 0L, dCodebook) == 0)
+    val words = new LongByReference()
+    val rc = lib.hf_encode(ctx, dData, n, layout, dCodebook, dSide, dPayload, payloadCapWords,
+                           dChunkOff, words)
+    require(rc == 0, s"hf_encode: $rc"); words.getValue
+  }
+}
 
-```python
-import torch
-from huffman_amd import api as hf
-w = torch.randn(1 << 24, device="cuda").mul_(0.02).to(torch.bfloat16)
-system, decoder = hf.EntropyAwareHuffmanSystem(), hf.ParrallelHuffmanDecoder()
-s = system.encode(w, mode=hf.HF_MODE_AUTO)        # stat -> sort -> entropy -> codebook -> pack
-print(s.ratio(), s.codebook.download()[2])        # ratio, compression_mode
-assert torch.equal(decoder.decode(s).view(torch.int16), w.view(torch.int16))
-```
-
-## C / C++
-
-```c
-#include "huffhip.h"
-hf_ctx* ctx; hf_ctx_create(&ctx, 0, stream);
-hf_symbol_stat_dev(ctx, d_w, n, HF_LAYOUT_BF16_EXP, d_freq);          /* d_freq zeroed by caller */
-hf_system_codebook_dev(ctx, d_freq, HF_MODE_HUFFMAN, 0, d_codebook);  /* 20 KiB device buffer   */
-uint64_t words;
-hf_encode(ctx, d_w, n, HF_LAYOUT_BF16_EXP, d_codebook, d_side, d_payload, cap_words, d_off, &words);
-hf_decode(ctx, d_payload, cap_words, d_off, d_side, n, HF_LAYOUT_BF16_EXP, d_codebook, d_out, 1);
-```
-
-Per-block codebooks (one codebook per 16384-symbol block, e.g. fp8 KV-cache pages) and
-decode-on-read of a list of blocks:
-
-```c
-hf_symbol_stat_chunks_dev(ctx, d_pages, n, HF_LAYOUT_FP8, d_freq_chunks);      /* u32[nchunks][256] */
-hf_system_codebook_chunks_dev(ctx, d_freq_chunks, nchunks, HF_MODE_AUTO, 0, d_cbs);
-hf_encode_chunks(ctx, d_pages, n, HF_LAYOUT_FP8, d_cbs, NULL, d_payload, cap_words, d_off, &words);
-/* all blocks in order ...                                                                      */
-hf_decode_chunks(ctx, d_payload, cap_words, d_off, NULL, n, HF_LAYOUT_FP8, d_cbs, NULL, 0, d_out, 1);
-/* ... or only the blocks named in d_ids (u32[n_ids]); block k of d_out is block d_ids[k]       */
-hf_decode_chunks(ctx, d_payload, cap_words, d_off, NULL, n, HF_LAYOUT_FP8, d_cbs, d_ids, n_ids, d_out2, 1);
-```
-
-`d_cbs` holds `HF_CHUNK_CODEBOOK_BYTES` (1552) per block. In Python:
-`s = system.encode_blocks(pages, mode=hf.HF_MODE_AUTO)`, `decoder.decode_blocks(s, chunk_ids=ids)`.
-
-Stored form (container, wire format v1 in `huffhip.h`): one blob with header, codebook(s),
-chunk offsets, side bytes and payload, decodable in place.
-
-```c
-hf_container_info info;
-hf_container_plan(n, HF_LAYOUT_BF16_EXP, HF_CODEBOOK_STREAM, words, &info);   /* sizes, offsets */
-hf_container_pack(ctx, &info, d_codebook, d_off, d_side, d_payload, d_blob, info.total_bytes);
-/* ... later, possibly in another process: */
-hf_container_open(ctx, d_blob, blob_bytes, &info);            /* validates the header            */
-hf_container_codebook(ctx, d_blob, &info, d_codebook2);       /* rebuilds the lookup tables      */
-hf_decode(ctx, (const uint32_t*)((char*)d_blob + info.off_payload),
-          (info.total_bytes - info.off_payload) / 4,
-          (const uint32_t*)((char*)d_blob + info.off_chunk_off),
-          (const uint8_t*)d_blob + info.off_side, info.n, info.layout, d_codebook2, d_out, 1);
-```
-
-Python: `blob = s.to_container()`; `s2 = hf.EncodedStream.from_container(blob)`;
-`decoder.decode(s2)` / `decoder.decode_blocks(s2, chunk_ids=ids)`.
-
-Buffer sizes: `d_side` n bytes (bf16 only); `d_off` `hf_num_chunks(n)+1` words; `d_payload`
-`hf_payload_bound_words(n)` words in the worst case (2 bytes per symbol), in practice
-`n/4 + 192·nchunks` words covers any codebook built from the data itself; a buffer that is too
-small is reported as `HF_ERR_OVERFLOW`, never overrun. The payload buffer handed to `hf_decode`
-must hold at least 4 words.
-
-## Multi-GPU
-
-One process per GPU; `huffman_amd/dist.py` gives the shard ranges and the one collective of
-global-codebook mode (`torch.distributed.all_reduce` of the int64[256] histogram, RCCL when the
-backend is `nccl`).
+/** Software twin of ParrallelHuffmanDecoder (decoder/top_decoder.scala:6; spelling as there). */
+class ParrallelHuffmanDecoder(val symWidth: Int = 8, val wtWidth: Int = 32, val depth: Int = 256,
+                              val maxCodeLen: Int = 16)(implicit ctx: Pointer) {
+  def decode(dPayload: Pointer, payloadWords: Long, dChunkOff: Pointer, dSide: Pointer, n: Long,
+             layout: Int, dCodebook: Pointer, dOut: Pointer): Unit = {
+    val rc = HuffHip.lib.hf_decode(ctx, dPayload, payloadWords, dChunkOff, dSide, n, layout,
+                                   dCodebook, dOut, 1)
+    require(rc == 0, s"hf_decode: $rc")
+  }
+}
