@@ -22,6 +22,7 @@ struct hf_ctx {
     uint32_t* d_ctl;    // [0] ticket, [1] error bits; 64-byte block
     uint32_t* h_ctl;    // pinned, 16 words
     uint32_t* d_spill;
+    void* d_cbscratch;  // per-block codebook batch scratch, allocated on first use
     hipEvent_t ev0, ev1;
     int timing;
     int timed;
@@ -157,6 +158,7 @@ int hf_ctx_destroy(hf_ctx* ctx) {
     if (ctx->d_ctl) (void)hipFree(ctx->d_ctl);
     if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
     if (ctx->d_spill) (void)hipFree(ctx->d_spill);
+    if (ctx->d_cbscratch) (void)hipFree(ctx->d_cbscratch);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -492,9 +494,12 @@ int hf_system_codebook_chunks_dev(hf_ctx* ctx, const uint32_t* d_freq_chunks, ui
     if (!aligned16(d_freq_chunks) || !aligned16(d_chunk_codebooks)) return HF_ERR_ALIGN;
     if (nchunks > 0x7FFFFFFFull) return HF_ERR_RANGE;
     if (int rc = use_device(ctx)) return rc;
+    if (nchunks && !ctx->d_cbscratch)
+        HF_HIP(hipMalloc(&ctx->d_cbscratch, hf_chunk_cb_scratch_bytes()));
     tic(ctx);
     hf_launch_system_chunks(d_freq_chunks, nchunks, mode, min_freq_threshold,
-                            reinterpret_cast<hf_chunk_cb*>(d_chunk_codebooks), ctx->stream);
+                            reinterpret_cast<hf_chunk_cb*>(d_chunk_codebooks), ctx->d_cbscratch,
+                            ctx->stream);
     toc(ctx);
     HF_HIP(hipGetLastError());
     return HF_OK;
