@@ -24,6 +24,7 @@ constexpr int kStageSlack = 64;    // never staged: room for the reads of a clam
 
 // Tables of a stream-wide codebook (any prefix-free code): shared by the workgroup.
 struct DecTables {
+    static constexpr int kBits = HF_LUT_BITS;
     uint16_t lut[HF_LUT_SIZE];  // first level, by the next 12 bits
     uint16_t sub[256 * 16];     // second level, 16 entries per escape, by the following 4 bits
 
@@ -37,14 +38,18 @@ struct DecTables {
 };
 
 // Tables of one chunk's codebook, rebuilt by the decoding wavefront from the canonical order:
-// a private first-level table plus, for the codes of 13..16 bits, the start/end of each
-// length's block in the left-aligned 16-bit code space and the rank of its first code.
+// a private first-level table of kBits bits (11, half the stream-wide one: the tables are per
+// wavefront, and LDS per wavefront is what bounds how many chunks a CU decodes at once) plus,
+// for the longer codes, either a direct table over their part of the 16-bit code space or, when
+// that part is too large, the start/end of each length's block and the rank of its first code.
 struct ChunkTables {
-    const uint16_t* lut;     // LDS, HF_LUT_SIZE entries of this wavefront
+    static constexpr int kBits = 11;
+    static constexpr int kLong = 16 - kBits;  // code lengths kBits+1 .. 16
+    const uint16_t* lut;     // LDS, 1 << kBits entries of this wavefront
     const uint8_t* rank2sym; // LDS, 256 entries
-    const uint16_t* tail;    // LDS, direct table over the code space of the 13..16-bit codes
+    const uint16_t* tail;    // LDS, direct table over the code space of the long codes
     uint32_t tail_n;         // entries of `tail` in use; 0: that space is too large, use the blocks
-    uint32_t start[4], end[4], off[4];  // lengths 13, 14, 15, 16 (wave-uniform)
+    uint32_t start[kLong], end[kLong], off[kLong];  // per long length (wave-uniform)
 
     __device__ __forceinline__ uint32_t long_code(const uint32_t top, const uint32_t,
                                                   uint32_t& len) const {
@@ -58,10 +63,10 @@ struct ChunkTables {
         uint32_t p = 0;
         len = 0;
 #pragma unroll
-        for (int k = 3; k >= 0; --k) {  // the lowest matching block wins
+        for (int k = kLong - 1; k >= 0; --k) {  // the lowest matching block wins
             if (v16 < end[k]) {
-                len = 13u + k;
-                p = off[k] + ((v16 - start[k]) >> (3 - k));
+                len = (uint32_t)(kBits + 1 + k);
+                p = off[k] + ((v16 - start[k]) >> (kLong - 1 - k));
             }
         }
         return rank2sym[p & 255u];
@@ -76,7 +81,7 @@ struct ChunkTables {
 template <class TAB>
 __device__ __forceinline__ uint32_t decode_one(u64& win, int& room, const TAB& T, uint32_t* err) {
     const uint32_t top = (uint32_t)(win >> 32);
-    uint32_t e = T.lut[top >> (32 - HF_LUT_BITS)];
+    uint32_t e = T.lut[top >> (32 - TAB::kBits)];
     if (__builtin_expect((e & 0xFFu) == 0, 0)) {
         uint32_t len;
         const uint32_t sym = T.long_code(top, e >> 8, len);
@@ -308,17 +313,20 @@ constexpr int kWavesC = 4;
 // Rebuild one chunk's decode tables from its canonical order.  Lane l holds ranks 4l .. 4l+3.
 // The codes of ranks 0, 1, 2, ... tile the left-aligned 16-bit code space front to back, rank p
 // covering 2^(16 - len_p) values, so a prefix sum of those widths gives every code.
-constexpr int kTailEntries = 1024;  // direct table for the long codes when their space fits
+constexpr int kTailEntries = 768;  // direct table for the long codes when their space fits
 
+// `tmp` (256 words) may alias the payload window: it is only used before the window is staged.
 __device__ void build_chunk_tables(const hf_chunk_cb* __restrict__ ccb, uint16_t* __restrict__ lut,
                                    uint8_t* __restrict__ r2s, uint32_t* __restrict__ tmp,
                                    uint16_t* __restrict__ tail, ChunkTables& T, const int lane) {
+    constexpr int B = ChunkTables::kBits;
+    constexpr int kLong = ChunkTables::kLong;
     const uint32_t lens4 = reinterpret_cast<const uint32_t*>(ccb->len_by_rank)[lane];
     const uint32_t syms4 = reinterpret_cast<const uint32_t*>(ccb->rank2sym)[lane];
     reinterpret_cast<uint32_t*>(r2s)[lane] = syms4;
     // zero the first level: entries no short code covers stay "escape"
 #pragma unroll
-    for (int k = 0; k < HF_LUT_SIZE * 2 / 16 / 64; ++k)
+    for (int k = 0; k < (1 << B) * 2 / 16 / 64; ++k)
         reinterpret_cast<uint4*>(lut)[k * 64 + lane] = make_uint4(0, 0, 0, 0);
     uint32_t len[4], width[4], start[4];
     uint32_t lane_total = 0;
@@ -336,38 +344,39 @@ __device__ void build_chunk_tables(const hf_chunk_cb* __restrict__ ccb, uint16_t
         if (lane >= o) incl += v;
     }
     const uint32_t lane_base = incl - lane_total;
-    // counts per length -> blocks of the 13..16-bit codes
+    // counts per length -> blocks of the long codes
     uint32_t cnt_below = 0, start_acc = 0;
     for (uint32_t d = 1; d <= 16; ++d) {
         uint32_t c = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) c += (uint32_t)__popcll(__ballot(len[i] == d));
-        if (d >= 13) {
-            T.start[d - 13] = start_acc;
-            T.off[d - 13] = cnt_below;
-            T.end[d - 13] = start_acc + (c << (16 - d));
+        if (d > (uint32_t)B) {
+            T.start[d - B - 1] = start_acc;
+            T.off[d - B - 1] = cnt_below;
+            T.end[d - B - 1] = start_acc + (c << (16 - d));
         }
         cnt_below += c;
         start_acc += c << (16 - d);
     }
-    // Codes of 13..16 bits occupy [start[0], end[3]) of the 16-bit code space; when that is at
+    // The long codes occupy [start[0], end[kLong-1]) of the 16-bit code space; when that is at
     // most kTailEntries values (rare symbols: the usual case) they get a direct table, so a long
     // code costs one more lookup instead of the block arithmetic.
-    const uint32_t tail_span = T.end[3] - T.start[0];
+    const uint32_t tail_span = T.end[kLong - 1] - T.start[0];
     T.tail_n = tail_span <= (uint32_t)kTailEntries ? tail_span : 0u;
     if (T.tail_n != 0) {
 #pragma unroll
-        for (int k = 0; k < kTailEntries * 2 / 16 / 64; ++k)
-            reinterpret_cast<uint4*>(tail)[k * 64 + lane] = make_uint4(0, 0, 0, 0);
+        for (int k = 0; k < kTailEntries * 2 / 16 / 32; ++k)
+            if (k * 64 + lane < kTailEntries * 2 / 16)
+                reinterpret_cast<uint4*>(tail)[k * 64 + lane] = make_uint4(0, 0, 0, 0);
     }
     // per-rank fill descriptor for the cooperative phase: first entry | len << 12 | sym << 24
-    uint32_t n_wide = 0;  // ranks with span >= 64 (len <= 6); they are the first ranks
+    uint32_t n_wide = 0;  // ranks with span >= 64 (len <= B - 6); they are the first ranks
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t s16 = lane_base + start[i];
         const uint32_t sym = (syms4 >> (8 * i)) & 0xFFu;
-        tmp[lane * 4 + i] = ((s16 >> 4) & 0xFFFu) | (len[i] << 12) | (sym << 24);
-        n_wide += (uint32_t)__popcll(__ballot(len[i] >= 1 && len[i] <= 6));
+        tmp[lane * 4 + i] = ((s16 >> (16 - B)) & ((1u << B) - 1u)) | (len[i] << 12) | (sym << 24);
+        n_wide += (uint32_t)__popcll(__ballot(len[i] >= 1 && len[i] <= B - 6));
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -377,21 +386,20 @@ __device__ void build_chunk_tables(const hf_chunk_cb* __restrict__ ccb, uint16_t
         const uint32_t d = tmp[q];
         const uint32_t first = d & 0xFFFu, L = (d >> 12) & 0x1Fu;
         const uint16_t val = (uint16_t)(((d >> 24) << 8) | L);
-        const uint32_t span = 1u << (HF_LUT_BITS - L);
+        const uint32_t span = 1u << (B - L);
         for (uint32_t k = lane; k < span; k += 64) lut[first + k] = val;
     }
-    // narrow codes (7..12 bits, at most 32 entries each): every lane fills its own ranks
+    // narrow codes (at most 32 entries each): every lane fills its own ranks
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        if (len[i] >= 7 && len[i] <= HF_LUT_BITS) {
-            const uint32_t first = ((lane_base + start[i]) >> 4) & 0xFFFu;
-            const uint16_t val = (uint16_t)((((syms4 >> (8 * i)) & 0xFFu) << 8) | len[i]);
-            const uint32_t span = 1u << (HF_LUT_BITS - len[i]);
+        const uint16_t val = (uint16_t)((((syms4 >> (8 * i)) & 0xFFu) << 8) | len[i]);
+        if (len[i] >= B - 5 && len[i] <= B) {
+            const uint32_t first = ((lane_base + start[i]) >> (16 - B)) & ((1u << B) - 1u);
+            const uint32_t span = 1u << (B - len[i]);
             for (uint32_t k = 0; k < span; ++k) lut[first + k] = val;
         }
-        if (T.tail_n != 0 && len[i] > HF_LUT_BITS && len[i] <= 16) {
+        if (T.tail_n != 0 && len[i] > B && len[i] <= 16) {
             const uint32_t first = lane_base + start[i] - T.start[0];
-            const uint16_t val = (uint16_t)((((syms4 >> (8 * i)) & 0xFFu) << 8) | len[i]);
             const uint32_t span = 1u << (16 - len[i]);
             for (uint32_t k = 0; k < span; ++k) tail[first + k] = val;
         }
@@ -411,9 +419,8 @@ __global__ __launch_bounds__(kWavesC * 64) void hf_k_decode_chunks(
     const uint32_t nchunks, const hf_chunk_cb* __restrict__ cbs,
     const uint32_t* __restrict__ chunk_ids, const uint32_t n_work, void* __restrict__ out,
     uint32_t* err) {
-    __shared__ __attribute__((aligned(16))) uint16_t lut_all[kWavesC][HF_LUT_SIZE];
+    __shared__ __attribute__((aligned(16))) uint16_t lut_all[kWavesC][1 << ChunkTables::kBits];
     __shared__ __attribute__((aligned(16))) uint32_t stage[kWavesC][kStageWords + kStageSlack];
-    __shared__ __attribute__((aligned(16))) uint32_t tmp_all[kWavesC][256];
     __shared__ __attribute__((aligned(16))) uint8_t r2s_all[kWavesC][256];
     __shared__ __attribute__((aligned(16))) uint16_t tail_all[kWavesC][kTailEntries];
     const int lane = hf_lane();
@@ -440,7 +447,8 @@ __global__ __launch_bounds__(kWavesC * 64) void hf_k_decode_chunks(
             continue;
         }
         ChunkTables T;
-        build_chunk_tables(cbs + c, lut_all[wv], r2s_all[wv], tmp_all[wv], tail_all[wv], T, lane);
+        // (the fill descriptors of the build borrow the payload window, staged only afterwards)
+        build_chunk_tables(cbs + c, lut_all[wv], r2s_all[wv], stage[wv], tail_all[wv], T, lane);
         const uint8_t* side_chunk = side ? side + first : nullptr;
         const uint64_t out_first = chunk_ids ? (uint64_t)k * HF_CHUNK_SYMS : first;
         void* out_chunk = reinterpret_cast<uint8_t*>(out) + out_first * elem_bytes;
@@ -469,7 +477,7 @@ void hf_launch_decode_chunks(const uint32_t* d_payload, uint64_t payload_words,
     const uint64_t n_work = d_chunk_ids ? n_ids : nchunks;
     if (n_work == 0) return;
     uint64_t grid = (n_work + kWavesC - 1) / kWavesC;
-    const uint64_t cap = (uint64_t)num_cu * 2;  // two 66 KiB workgroups fit one CU's LDS
+    const uint64_t cap = (uint64_t)num_cu * 3;  // three 52 KiB workgroups fit one CU's LDS
     if (grid > cap) grid = cap;
     if (layout == HF_LAYOUT_BF16_EXP)
         hipLaunchKernelGGL(hf_k_decode_chunks<HF_LAYOUT_BF16_EXP>, dim3((unsigned)grid),
