@@ -19,12 +19,14 @@ namespace {
 
 typedef unsigned long long u64;
 constexpr int kWaves = 8;
-constexpr int kStageWords = 1792;  // payload window per wavefront (7 KiB)
+constexpr int kStageWords = 1792;   // payload window per wavefront, stream-wide tables (7 KiB)
+constexpr int kStageWordsC = 1024;  // payload window per wavefront, per-chunk tables (4 KiB)
 constexpr int kStageSlack = 64;    // never staged: room for the reads of a clamped position
 
 // Tables of a stream-wide codebook (any prefix-free code): shared by the workgroup.
 struct DecTables {
     static constexpr int kBits = HF_LUT_BITS;
+    static constexpr int kStage = kStageWords;
     uint16_t lut[HF_LUT_SIZE];  // first level, by the next 12 bits
     uint16_t sub[256 * 16];     // second level, 16 entries per escape, by the following 4 bits
 
@@ -44,6 +46,7 @@ struct DecTables {
 // that part is too large, the start/end of each length's block and the rank of its first code.
 struct ChunkTables {
     static constexpr int kBits = 11;
+    static constexpr int kStage = kStageWordsC;
     static constexpr int kLong = 16 - kBits;  // code lengths kBits+1 .. 16
     const uint16_t* lut;     // LDS, 1 << kBits entries of this wavefront
     const uint8_t* rank2sym; // LDS, 256 entries
@@ -96,27 +99,29 @@ __device__ __forceinline__ uint32_t decode_one(u64& win, int& room, const TAB& T
     return e;
 }
 
-// Copy payload words [gs, gs + kStageWords) into the wavefront's LDS window; gs is a multiple
-// of 4 so every access is a 16-byte one.  Words past the payload buffer read as zero.
+// Copy payload words [gs, gs + W) into the wavefront's LDS window; gs is a multiple of 4 so
+// every access is a 16-byte one.  Words past the payload buffer read as zero.
+template <int W>
 __device__ __forceinline__ void stage_window(const uint32_t* __restrict__ payload,
                                              const u64 payload_words, const u64 gs,
                                              uint32_t* __restrict__ stg, const int lane) {
     // Loads past the buffer are redirected to its last 16 bytes (a well-formed chunk never
     // consumes those words), so all eight loads are issued back to back without branches.
     const u64 last = (payload_words - 4) & ~3ull;  // the caller guarantees payload_words >= 4
-    uint4 v[kStageWords / 256];
+    uint4 v[W / 256];
 #pragma unroll
-    for (int k = 0; k < kStageWords / 256; ++k) {
+    for (int k = 0; k < W / 256; ++k) {
         u64 idx = gs + (u64)(k * 256 + lane * 4);
         idx = idx < last ? idx : last;
         v[k] = *reinterpret_cast<const uint4*>(payload + idx);
     }
 #pragma unroll
-    for (int k = 0; k < kStageWords / 256; ++k)
+    for (int k = 0; k < W / 256; ++k)
         *reinterpret_cast<uint4*>(stg + k * 256 + lane * 4) = v[k];
 }
 
 // refill step shared by both paths: lanes in `need` take consecutive words from the window
+template <int W>
 __device__ __forceinline__ void refill(const bool need, u64& win, int& room, uint32_t& lpos,
                                        const uint32_t* __restrict__ stg) {
     const u64 m = __ballot(need);
@@ -124,7 +129,7 @@ __device__ __forceinline__ void refill(const bool need, u64& win, int& room, uin
         // window index = lpos + (needing lanes below this one); v_mbcnt accumulates onto the
         // base.  A well-formed chunk never moves lpos past the staged words; the scalar clamp
         // plus the kStageSlack words behind the window keep a corrupt one inside the array.
-        const uint32_t base = lpos < (uint32_t)kStageWords ? lpos : (uint32_t)kStageWords;
+        const uint32_t base = lpos < (uint32_t)W ? lpos : (uint32_t)W;
         const uint32_t idx = __builtin_amdgcn_mbcnt_hi(
             (uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, base));
         const uint32_t w = stg[idx];
@@ -144,7 +149,7 @@ __device__ u64 decode_chunk_full(const uint32_t* __restrict__ payload, const u64
                                  void* __restrict__ out_chunk, const TAB& T,
                                  uint32_t* __restrict__ stg, uint32_t* err, const int lane) {
     u64 gs = off0 & ~3ull;
-    stage_window(payload, payload_words, gs, stg, lane);
+    stage_window<TAB::kStage>(payload, payload_words, gs, stg, lane);
     uint32_t lpos = (uint32_t)(off0 - gs);  // window index of the next unread word
     u64 win = 0;                            // buffered bits, MSB aligned
     int room = 32;                          // 32 - buffered bit count
@@ -163,15 +168,15 @@ __device__ u64 decode_chunk_full(const uint32_t* __restrict__ payload, const u64
     }
     auto round = [&](const uint32_t r, hf_u32x2& sd) {
         // a round takes at most 4 x 64 words: slide the window when it could run out
-        if (lpos + 256u > (uint32_t)kStageWords && gs + kStageWords < off1) {
+        if (lpos + 256u > (uint32_t)TAB::kStage && gs + TAB::kStage < off1) {
             gs = (gs + lpos) & ~3ull;
             lpos = lpos & 3u;
-            stage_window(payload, payload_words, gs, stg, lane);
+            stage_window<TAB::kStage>(payload, payload_words, gs, stg, lane);
         }
         uint32_t e[8];  // table entries: symbol in byte 1
 #pragma unroll
         for (int jp = 0; jp < 4; ++jp) {
-            refill(room > 0, win, room, lpos, stg);
+            refill<TAB::kStage>(room > 0, win, room, lpos, stg);
             e[2 * jp] = decode_one(win, room, T, err);
             e[2 * jp + 1] = decode_one(win, room, T, err);
         }
@@ -220,24 +225,24 @@ __device__ u64 decode_chunk_tail(const uint32_t* __restrict__ payload, const u64
                                  const TAB& T, uint32_t* __restrict__ stg, uint32_t* err,
                                  const int lane) {
     u64 gs = off0 & ~3ull;
-    stage_window(payload, payload_words, gs, stg, lane);
+    stage_window<TAB::kStage>(payload, payload_words, gs, stg, lane);
     uint32_t lpos = (uint32_t)(off0 - gs);
     u64 win = 0;
     int room = 32;
     const uint32_t rounds = (nvalid + 511u) / 512u;
     for (uint32_t r = 0; r < rounds; ++r) {
         const uint32_t g = r * 64u + lane;
-        if (lpos + 256u > (uint32_t)kStageWords && gs + kStageWords < off1) {
+        if (lpos + 256u > (uint32_t)TAB::kStage && gs + TAB::kStage < off1) {
             gs = (gs + lpos) & ~3ull;
             lpos = lpos & 3u;
-            stage_window(payload, payload_words, gs, stg, lane);
+            stage_window<TAB::kStage>(payload, payload_words, gs, stg, lane);
         }
         uint32_t s[8];
 #pragma unroll
         for (int jp = 0; jp < 4; ++jp) {
             const uint32_t i0 = g * 8 + 2 * jp;
             const bool va = i0 < nvalid, vb = i0 + 1 < nvalid;
-            refill(va && room > 0, win, room, lpos, stg);
+            refill<TAB::kStage>(va && room > 0, win, room, lpos, stg);
             s[2 * jp] = va ? decode_one(win, room, T, err) >> 8 : 0u;
             s[2 * jp + 1] = vb ? decode_one(win, room, T, err) >> 8 : 0u;
         }
@@ -313,7 +318,7 @@ constexpr int kWavesC = 4;
 // Rebuild one chunk's decode tables from its canonical order.  Lane l holds ranks 4l .. 4l+3.
 // The codes of ranks 0, 1, 2, ... tile the left-aligned 16-bit code space front to back, rank p
 // covering 2^(16 - len_p) values, so a prefix sum of those widths gives every code.
-constexpr int kTailEntries = 768;  // direct table for the long codes when their space fits
+constexpr int kTailEntries = 512;  // direct table for the long codes when their space fits
 
 // `tmp` (256 words) may alias the payload window: it is only used before the window is staged.
 __device__ void build_chunk_tables(const hf_chunk_cb* __restrict__ ccb, uint16_t* __restrict__ lut,
@@ -420,7 +425,7 @@ __global__ __launch_bounds__(kWavesC * 64) void hf_k_decode_chunks(
     const uint32_t* __restrict__ chunk_ids, const uint32_t n_work, void* __restrict__ out,
     uint32_t* err) {
     __shared__ __attribute__((aligned(16))) uint16_t lut_all[kWavesC][1 << ChunkTables::kBits];
-    __shared__ __attribute__((aligned(16))) uint32_t stage[kWavesC][kStageWords + kStageSlack];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[kWavesC][kStageWordsC + kStageSlack];
     __shared__ __attribute__((aligned(16))) uint8_t r2s_all[kWavesC][256];
     __shared__ __attribute__((aligned(16))) uint16_t tail_all[kWavesC][kTailEntries];
     const int lane = hf_lane();
@@ -477,7 +482,7 @@ void hf_launch_decode_chunks(const uint32_t* d_payload, uint64_t payload_words,
     const uint64_t n_work = d_chunk_ids ? n_ids : nchunks;
     if (n_work == 0) return;
     uint64_t grid = (n_work + kWavesC - 1) / kWavesC;
-    const uint64_t cap = (uint64_t)num_cu * 3;  // three 52 KiB workgroups fit one CU's LDS
+    const uint64_t cap = (uint64_t)num_cu * 4;  // four 40 KiB workgroups fit one CU's LDS
     if (grid > cap) grid = cap;
     if (layout == HF_LAYOUT_BF16_EXP)
         hipLaunchKernelGGL(hf_k_decode_chunks<HF_LAYOUT_BF16_EXP>, dim3((unsigned)grid),
