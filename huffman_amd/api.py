@@ -33,8 +33,14 @@ def _ptr(a: np.ndarray, t):
 
 
 def layout_of(t: torch.Tensor) -> int:
-    """bf16 tensors are coded by exponent byte, 8-bit tensors byte by byte."""
-    if t.dtype == torch.bfloat16:
+    """16-bit words are split into a coded byte and a raw byte, 8-bit tensors coded byte by byte.
+
+    The 16-bit split (symbol = bits 14..7, raw byte = bit 15 and bits 6..0) puts the whole
+    exponent of a bf16 word into the symbol; of an fp16 word it takes the 5 exponent bits and the
+    3 leading mantissa bits, which costs nothing in size (those bits code at about 3 bits) and is
+    exactly reversible, so fp16 and 16-bit integer tensors go through the same kernels.
+    """
+    if t.dtype in (torch.bfloat16, torch.float16, torch.int16):
         return HF_LAYOUT_BF16_EXP
     if t.dtype in (torch.uint8, torch.int8):
         return HF_LAYOUT_U8

@@ -250,11 +250,44 @@ def test_encode_decode_skewed(hf, orc, kind, n):
     system_roundtrip(hf, orc, dev_u8(sym), sym, mode=hf.HF_MODE_HUFFMAN)
 
 
+@pytest.mark.parametrize("kind", ["geometric", "one", "two", "fib", "equal"])
+def test_encode_decode_64mib_block(hf, orc, kind):
+    # the degenerate count shapes at the large block size: 64 MiB of byte symbols, whole payload
+    # compared with the oracle's
+    n = 64 << 20
+    if kind == "equal":
+        sym = np.tile(np.arange(256, dtype=np.uint8), n // 256)
+    else:
+        sym = skewed_symbols(n, 23, kind)
+    s = system_roundtrip(hf, orc, dev_u8(sym), sym, mode=hf.HF_MODE_HUFFMAN)
+    lens = s.codebook.download()[1]
+    assert lens.max() <= 16 and kraft(lens) <= 1.0
+    if kind == "fib":
+        assert lens.max() == 16  # the unconstrained tree is deeper; the limiter was at work
+
+
 @pytest.mark.parametrize("n", [1, 8, 1000, 16384, 16384 * 5 + 13, 1 << 20])
 def test_encode_decode_bf16(hf, orc, n):
     w = gaussian_bf16(n, seed=n + 1)
     sym, side = orc.symbolize(w, orc.LAYOUT_BF16_EXP)
     system_roundtrip(hf, orc, dev_bf16(w), sym, mode=hf.HF_MODE_HUFFMAN, side=side)
+
+
+def test_fp16_and_int16_words_use_the_16_bit_split(hf, orc):
+    # fp16: symbol = 5 exponent bits + 3 mantissa bits, raw byte = sign + 7 mantissa bits
+    rng = np.random.default_rng(5)
+    w = (rng.standard_normal(300000) * 0.02).astype(np.float16).view(np.uint16)
+    sym, side = orc.symbolize(w, orc.LAYOUT_BF16_EXP)
+    t = torch.from_numpy(w.view(np.int16)).to(DEV)
+    for data in (t.view(torch.float16), t):
+        s = system_roundtrip(hf, orc, data, sym, mode=hf.HF_MODE_HUFFMAN, side=side)
+        assert s.dtype == data.dtype
+        assert s.compressed_bytes() < 2 * w.size * 0.9
+    # two fp4 values per byte are byte symbols
+    p4 = np.clip(np.round(rng.standard_normal(200000) * 2), -7, 7).astype(np.int8) & 0xF
+    packed = (p4[0::2] | (p4[1::2] << 4)).astype(np.uint8)
+    s = system_roundtrip(hf, orc, dev_u8(packed), packed, mode=hf.HF_MODE_HUFFMAN)
+    assert s.compressed_bytes() < packed.size * 0.8
 
 
 def test_empty_stream(hf):
