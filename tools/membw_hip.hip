@@ -1,0 +1,148 @@
+// Plain streaming rates of one GPU with hand-written kernels: what a copy, a read and a fill reach
+// with ordinary and with non-temporal accesses, at several loads in flight per lane.  The numbers
+// say how far the coding kernels are from what the memory system gives a kernel that does nothing
+// but move bytes.   Build: hipcc -O3 --offload-arch=gfx950 tools/membw_hip.hip -o tools/membw_hip
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define CK(x)                                                                       \
+    do {                                                                            \
+        hipError_t e_ = (x);                                                        \
+        if (e_ != hipSuccess) {                                                     \
+            fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            exit(1);                                                                \
+        }                                                                           \
+    } while (0)
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NT>
+__device__ __forceinline__ u32x4 ld(const u32x4* p) {
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+template <int NT>
+__device__ __forceinline__ void st(u32x4* p, u32x4 v) {
+    if (NT)
+        __builtin_nontemporal_store(v, p);
+    else
+        *p = v;
+}
+
+// each workgroup walks tiles of 256 * K vectors; K loads in flight per lane
+template <int K, int NTL, int NTS>
+__global__ __launch_bounds__(256) void k_copy(const u32x4* __restrict__ src, u32x4* __restrict__ dst,
+                                              size_t nvec) {
+    const size_t tile = (size_t)256 * K;
+    for (size_t base = (size_t)blockIdx.x * tile; base + tile <= nvec; base += (size_t)gridDim.x * tile) {
+        u32x4 v[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = ld<NTL>(src + base + k * 256 + threadIdx.x);
+#pragma unroll
+        for (int k = 0; k < K; ++k) st<NTS>(dst + base + k * 256 + threadIdx.x, v[k]);
+    }
+}
+
+template <int K, int NTL>
+__global__ __launch_bounds__(256) void k_read(const u32x4* __restrict__ src, uint32_t* __restrict__ out,
+                                              size_t nvec) {
+    const size_t tile = (size_t)256 * K;
+    uint32_t acc = 0;
+    for (size_t base = (size_t)blockIdx.x * tile; base + tile <= nvec; base += (size_t)gridDim.x * tile) {
+        u32x4 v[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = ld<NTL>(src + base + k * 256 + threadIdx.x);
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc += v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+    }
+    if (acc == 0x12345678u) out[0] = acc;  // keeps the loads alive
+}
+
+template <int K, int NTS>
+__global__ __launch_bounds__(256) void k_fill(u32x4* __restrict__ dst, size_t nvec) {
+    const size_t tile = (size_t)256 * K;
+    const u32x4 v = {threadIdx.x, blockIdx.x, 3u, 4u};
+    for (size_t base = (size_t)blockIdx.x * tile; base + tile <= nvec; base += (size_t)gridDim.x * tile) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) st<NTS>(dst + base + k * 256 + threadIdx.x, v);
+    }
+}
+
+// the decoder's mix: read R vectors, write W vectors per tile step (R:W = 2:3 ~ 1.33 B in, 2 B out)
+template <int R, int W, int NTL, int NTS>
+__global__ __launch_bounds__(256) void k_mix(const u32x4* __restrict__ src, u32x4* __restrict__ dst,
+                                             size_t nsteps) {
+    for (size_t s = blockIdx.x; s < nsteps; s += gridDim.x) {
+        u32x4 v[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) v[k] = ld<NTL>(src + (s * R + k) * 256 + threadIdx.x);
+#pragma unroll
+        for (int k = 0; k < W; ++k) st<NTS>(dst + (s * W + k) * 256 + threadIdx.x, v[k % R]);
+    }
+}
+
+template <typename F>
+static double time_ms(F launch, int reps) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) launch();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a, 0));
+    for (int i = 0; i < reps; ++i) launch();
+    CK(hipEventRecord(b, 0));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    CK(hipGetLastError());
+    return ms / reps;
+}
+
+int main(int argc, char** argv) {
+    const size_t bytes = (argc > 1 ? (size_t)atoll(argv[1]) : 4096) << 20;  // MiB per buffer
+    const size_t nvec = bytes / 16;
+    void *src, *dst;
+    CK(hipMalloc(&src, bytes));
+    CK(hipMalloc(&dst, bytes));
+    CK(hipMemset(src, 1, bytes));
+    CK(hipMemset(dst, 2, bytes));
+    hipDeviceProp_t p;
+    CK(hipGetDeviceProperties(&p, 0));
+    const int cu = p.multiProcessorCount;
+    printf("%s, %d CUs, %zu MiB per buffer\n", p.name, cu, bytes >> 20);
+    const int reps = 10;
+    const double gb = (double)bytes / 1e9;
+#define ROW(name, traffic_gb, ...)                                        \
+    {                                                                     \
+        double ms = time_ms([&] { __VA_ARGS__; }, reps);                  \
+        printf("%-34s %8.3f ms %8.0f GB/s\n", name, ms, (traffic_gb) / ms * 1e3); \
+    }
+    for (int wg_per_cu : {4, 8, 16, 0}) {
+        const unsigned g = wg_per_cu ? (unsigned)(cu * wg_per_cu) : (unsigned)(nvec / (256 * 4));
+        printf("-- grid %u (%d workgroups per CU%s)\n", g, wg_per_cu, wg_per_cu ? "" : ": one tile each");
+        ROW("copy  K=4 plain", 2 * gb, (k_copy<4, 0, 0><<<g, 256>>>((const u32x4*)src, (u32x4*)dst, nvec)));
+        ROW("copy  K=4 nt-store", 2 * gb, (k_copy<4, 0, 1><<<g, 256>>>((const u32x4*)src, (u32x4*)dst, nvec)));
+        ROW("copy  K=4 nt-load nt-store", 2 * gb, (k_copy<4, 1, 1><<<g, 256>>>((const u32x4*)src, (u32x4*)dst, nvec)));
+        ROW("copy  K=8 plain", 2 * gb, (k_copy<8, 0, 0><<<g, 256>>>((const u32x4*)src, (u32x4*)dst, nvec)));
+        ROW("copy  K=8 nt-load nt-store", 2 * gb, (k_copy<8, 1, 1><<<g, 256>>>((const u32x4*)src, (u32x4*)dst, nvec)));
+        ROW("read  K=4 plain", gb, (k_read<4, 0><<<g, 256>>>((const u32x4*)src, (uint32_t*)dst, nvec)));
+        ROW("read  K=8 plain", gb, (k_read<8, 0><<<g, 256>>>((const u32x4*)src, (uint32_t*)dst, nvec)));
+        ROW("read  K=8 nt", gb, (k_read<8, 1><<<g, 256>>>((const u32x4*)src, (uint32_t*)dst, nvec)));
+        ROW("fill  K=4 plain", gb, (k_fill<4, 0><<<g, 256>>>((u32x4*)dst, nvec)));
+        ROW("fill  K=4 nt", gb, (k_fill<4, 1><<<g, 256>>>((u32x4*)dst, nvec)));
+        {
+            const size_t steps = nvec / (256 * 3);
+            const double t = (double)steps * 256 * 16 * 5 / 1e9;
+            ROW("mix 2 read : 3 written plain", t, (k_mix<2, 3, 0, 0><<<g, 256>>>((const u32x4*)src, (u32x4*)dst, steps)));
+            ROW("mix 2 read : 3 written nt", t, (k_mix<2, 3, 1, 1><<<g, 256>>>((const u32x4*)src, (u32x4*)dst, steps)));
+            ROW("mix 3 read : 2 written plain", t, (k_mix<3, 2, 0, 0><<<g, 256>>>((const u32x4*)src, (u32x4*)dst, steps)));
+            ROW("mix 3 read : 2 written nt", t, (k_mix<3, 2, 1, 1><<<g, 256>>>((const u32x4*)src, (u32x4*)dst, steps)));
+        }
+    }
+    ROW("hipMemcpyDtoD", 2 * gb, CK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, 0)));
+    CK(hipFree(src));
+    CK(hipFree(dst));
+    return 0;
+}
