@@ -108,36 +108,47 @@ __global__ __launch_bounds__(kChunkWaves * 64) void hf_k_hist_chunks(
     const uint64_t left = n - first;
     const uint32_t nvalid = left < HF_CHUNK_SYMS ? (uint32_t)left : HF_CHUNK_SYMS;
     const uint32_t copy = lane & (kChunkCopies - 1);
-    if (LAYOUT == HF_LAYOUT_BF16_EXP) {
-        const uint16_t* p16 = reinterpret_cast<const uint16_t*>(data) + first;
-        const uint32_t nvec = nvalid / 8;
-        for (uint32_t v = lane; v < nvec; v += 64) {
-            const uint4 x = reinterpret_cast<const uint4*>(p16)[v];
-            const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+    const uint4* const pv = reinterpret_cast<const uint4*>(
+        reinterpret_cast<const uint8_t*>(data) + first * (LAYOUT == HF_LAYOUT_BF16_EXP ? 2 : 1));
+    constexpr uint32_t kPerVec = LAYOUT == HF_LAYOUT_BF16_EXP ? 8 : 16;
+    auto count_vec = [&](const uint4 x) {
+        const uint32_t w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i) {
+            if (LAYOUT == HF_LAYOUT_BF16_EXP) {
                 atomicAdd(&h[((w[i] >> 7) & 0xFFu) * kChunkCopies + copy], 1u);
                 atomicAdd(&h[((w[i] >> 23) & 0xFFu) * kChunkCopies + copy], 1u);
-            }
-        }
-        for (uint32_t i = nvec * 8 + lane; i < nvalid; i += 64)
-            atomicAdd(&h[((p16[i] >> 7) & 0xFFu) * kChunkCopies + copy], 1u);
-    } else {
-        const uint8_t* p8 = reinterpret_cast<const uint8_t*>(data) + first;
-        const uint32_t nvec = nvalid / 16;
-        for (uint32_t v = lane; v < nvec; v += 64) {
-            const uint4 x = reinterpret_cast<const uint4*>(p8)[v];
-            const uint32_t w[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            } else {
                 atomicAdd(&h[(w[i] & 0xFFu) * kChunkCopies + copy], 1u);
                 atomicAdd(&h[((w[i] >> 8) & 0xFFu) * kChunkCopies + copy], 1u);
                 atomicAdd(&h[((w[i] >> 16) & 0xFFu) * kChunkCopies + copy], 1u);
                 atomicAdd(&h[(w[i] >> 24) * kChunkCopies + copy], 1u);
             }
         }
-        for (uint32_t i = nvec * 16 + lane; i < nvalid; i += 64)
-            atomicAdd(&h[p8[i] * kChunkCopies + copy], 1u);
+    };
+    if (nvalid == HF_CHUNK_SYMS) {
+        // a whole page: its loads are issued 16 at a time before any of them is consumed
+        constexpr int kBatch = 16;
+        constexpr int kBatches = HF_CHUNK_SYMS / kPerVec / 64 / kBatch;
+#pragma unroll 1
+        for (int b = 0; b < kBatches; ++b) {
+            uint4 x[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) x[k] = stream_load(pv + (b * kBatch + k) * 64 + lane);
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) count_vec(x[k]);
+        }
+    } else {
+        const uint32_t nvec = nvalid / kPerVec;
+        for (uint32_t v = lane; v < nvec; v += 64) count_vec(pv[v]);
+        for (uint32_t i = nvec * kPerVec + lane; i < nvalid; i += 64) {
+            if (LAYOUT == HF_LAYOUT_BF16_EXP) {
+                const uint16_t e = reinterpret_cast<const uint16_t*>(pv)[i];
+                atomicAdd(&h[((e >> 7) & 0xFFu) * kChunkCopies + copy], 1u);
+            } else {
+                atomicAdd(&h[reinterpret_cast<const uint8_t*>(pv)[i] * kChunkCopies + copy], 1u);
+            }
+        }
     }
     // the wavefront's own LDS operations complete in order; no other wavefront touches h
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
