@@ -19,7 +19,7 @@ namespace {
 
 typedef unsigned long long u64;
 constexpr int kWaves = 8;
-constexpr int kStageWords = 1792;   // payload window per wavefront, stream-wide tables (7 KiB)
+constexpr int kStageWords = 1024;   // payload window per wavefront, stream-wide tables (4 KiB)
 constexpr int kStageWordsC = 1024;  // payload window per wavefront, per-chunk tables (4 KiB)
 constexpr int kStageSlack = 64;    // never staged: room for the reads of a clamped position
 
@@ -502,7 +502,7 @@ void hf_launch_decode(const uint32_t* d_payload, uint64_t payload_words,
     const uint64_t nchunks = (n + HF_CHUNK_SYMS - 1) / HF_CHUNK_SYMS;
     if (nchunks == 0) return;
     uint64_t grid = (nchunks + kWaves - 1) / kWaves;
-    const uint64_t cap = (uint64_t)num_cu * 2;  // two 72 KiB workgroups fit one CU's LDS
+    const uint64_t cap = (uint64_t)num_cu * 3;  // three 50 KiB workgroups fit one CU's LDS
     if (grid > cap) grid = cap;
     if (layout == HF_LAYOUT_BF16_EXP)
         hipLaunchKernelGGL(hf_k_decode<HF_LAYOUT_BF16_EXP>, dim3((unsigned)grid),
