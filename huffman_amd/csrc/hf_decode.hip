@@ -6,9 +6,10 @@
 // lock step (layout: hf_encode.hip).  Before each pair of symbols the lanes holding fewer
 // than 32 buffered bits take the next payload words, lanes in ascending order, so the
 // wavefront consumes the payload strictly front to back.  The payload of a chunk is staged
-// into a 7 KiB LDS window with one burst of 16-byte loads (re-staged only when a chunk is
-// larger than the window), so the symbol loop itself issues no payload loads; side bytes are
+// into a 4 KiB LDS window with one burst of 16-byte loads (re-staged when a chunk is larger
+// than the window), so the symbol loop itself issues no payload loads; side bytes are
 // fetched two rounds ahead and outputs leave as one 16-byte store per lane and round.
+// Everything is touched once, so loads and stores are non-temporal.
 // A 12-bit first-level table in LDS resolves almost every symbol with one lookup; a longer
 // code takes one more lookup in a 16-entry second-level table named by the first.
 //
@@ -113,7 +114,8 @@ __device__ __forceinline__ void stage_window(const uint32_t* __restrict__ payloa
     for (int k = 0; k < W / 256; ++k) {
         u64 idx = gs + (u64)(k * 256 + lane * 4);
         idx = idx < last ? idx : last;
-        v[k] = *reinterpret_cast<const uint4*>(payload + idx);
+        const hf_u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const hf_u32x4*>(payload + idx));
+        v[k] = make_uint4(t.x, t.y, t.z, t.w);
     }
 #pragma unroll
     for (int k = 0; k < W / 256; ++k)
@@ -163,8 +165,8 @@ __device__ u64 decode_chunk_full(const uint32_t* __restrict__ payload, const u64
     // rounds ahead right after its use, so no register is rotated and every wait is counted
     hf_u32x2 sdA = {0u, 0u}, sdB = {0u, 0u};
     if (LAYOUT == HF_LAYOUT_BF16_EXP) {
-        sdA = *reinterpret_cast<const hf_gmem_u32x2*>(su + lane8);
-        sdB = *reinterpret_cast<const hf_gmem_u32x2*>(su + 512 + lane8);
+        sdA = __builtin_nontemporal_load(reinterpret_cast<const hf_gmem_u32x2*>(su + lane8));
+        sdB = __builtin_nontemporal_load(reinterpret_cast<const hf_gmem_u32x2*>(su + 512 + lane8));
     }
     auto round = [&](const uint32_t r, hf_u32x2& sd) {
         // a round takes at most 4 x 64 words: slide the window when it could run out
@@ -198,15 +200,17 @@ __device__ u64 decode_chunk_full(const uint32_t* __restrict__ payload, const u64
             }
             // side bytes for two rounds ahead; the last two rounds reload round 31's
             const uint32_t pf = r + 2u < HF_ROUNDS ? r + 2u : HF_ROUNDS - 1u;
-            sd = *reinterpret_cast<const hf_gmem_u32x2*>(su + pf * 512u + lane8);
-            *reinterpret_cast<hf_gmem_u32x4*>(ou + r * 1024u + lane16) = hf_u32x4{o[0], o[1], o[2], o[3]};
+            sd = __builtin_nontemporal_load(
+                reinterpret_cast<const hf_gmem_u32x2*>(su + pf * 512u + lane8));
+            __builtin_nontemporal_store(hf_u32x4{o[0], o[1], o[2], o[3]},
+                                        reinterpret_cast<hf_gmem_u32x4*>(ou + r * 1024u + lane16));
         } else {
             const uint32_t a = __builtin_amdgcn_perm(e[1], e[0], 0x0C0C0501u);
             const uint32_t b = __builtin_amdgcn_perm(e[3], e[2], 0x0C0C0501u);
             const uint32_t c = __builtin_amdgcn_perm(e[5], e[4], 0x0C0C0501u);
             const uint32_t d = __builtin_amdgcn_perm(e[7], e[6], 0x0C0C0501u);
-            *reinterpret_cast<hf_gmem_u32x2*>(ou + r * 512u + lane8) =
-                hf_u32x2{a | (b << 16), c | (d << 16)};
+            __builtin_nontemporal_store(hf_u32x2{a | (b << 16), c | (d << 16)},
+                                        reinterpret_cast<hf_gmem_u32x2*>(ou + r * 512u + lane8));
         }
     };
     for (uint32_t r = 0; r < HF_ROUNDS; r += 2) {
@@ -481,9 +485,9 @@ void hf_launch_decode_chunks(const uint32_t* d_payload, uint64_t payload_words,
     const uint64_t nchunks = (n + HF_CHUNK_SYMS - 1) / HF_CHUNK_SYMS;
     const uint64_t n_work = d_chunk_ids ? n_ids : nchunks;
     if (n_work == 0) return;
-    uint64_t grid = (n_work + kWavesC - 1) / kWavesC;
-    const uint64_t cap = (uint64_t)num_cu * 4;  // four 40 KiB workgroups fit one CU's LDS
-    if (grid > cap) grid = cap;
+    // one chunk per wavefront (four 38 KiB workgroups fit one CU's LDS)
+    (void)num_cu;
+    const uint64_t grid = (n_work + kWavesC - 1) / kWavesC;
     if (layout == HF_LAYOUT_BF16_EXP)
         hipLaunchKernelGGL(hf_k_decode_chunks<HF_LAYOUT_BF16_EXP>, dim3((unsigned)grid),
                            dim3(kWavesC * 64), 0, s, d_payload, payload_words, d_chunk_off, d_side,
@@ -501,9 +505,12 @@ void hf_launch_decode(const uint32_t* d_payload, uint64_t payload_words,
                       hipStream_t s) {
     const uint64_t nchunks = (n + HF_CHUNK_SYMS - 1) / HF_CHUNK_SYMS;
     if (nchunks == 0) return;
-    uint64_t grid = (nchunks + kWaves - 1) / kWaves;
-    const uint64_t cap = (uint64_t)num_cu * 3;  // three 50 KiB workgroups fit one CU's LDS
-    if (grid > cap) grid = cap;
+    // One chunk per wavefront, workgroups come and go (three 50 KiB workgroups fit one CU's LDS):
+    // measured 7-10 % faster on bf16 streams than a resident grid looping over the chunks, the
+    // same gain a kernel that only moves these bytes in this pattern shows; the price is one
+    // 16 KiB table copy out of L2 per eight chunks.
+    (void)num_cu;
+    const uint64_t grid = (nchunks + kWaves - 1) / kWaves;
     if (layout == HF_LAYOUT_BF16_EXP)
         hipLaunchKernelGGL(hf_k_decode<HF_LAYOUT_BF16_EXP>, dim3((unsigned)grid),
                            dim3(kWaves * 64), 0, s, d_payload, payload_words, d_chunk_off,

@@ -79,7 +79,52 @@ __global__ __launch_bounds__(256) void k_mix(const u32x4* __restrict__ src, u32x
 #pragma unroll
         for (int k = 0; k < R; ++k) v[k] = ld<NTL>(src + (s * R + k) * 256 + threadIdx.x);
 #pragma unroll
-        for (int k = 0; k < W; ++k) st<NTS>(dst + (s * W + k) * 256 + threadIdx.x, v[k % R]);
+        for (int k = 1; k < R; ++k) v[0] ^= v[k];  // every load is used
+#pragma unroll
+        for (int k = 0; k < W; ++k) st<NTS>(dst + (s * W + k) * 256 + threadIdx.x, v[0]);
+    }
+}
+
+// The coding kernels' pattern: one wavefront per 16384-element chunk, walking its own region 64
+// lanes x 16 bytes (16-bit side) or x 8 bytes (byte side) per round, eight rounds in flight.
+// DEC: read the byte side, write the 16-bit side; otherwise the reverse.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <int DEC, int NT>
+__global__ __launch_bounds__(256) void k_wave_chunks(const uint8_t* __restrict__ src,
+                                                     uint8_t* __restrict__ dst, size_t nchunks) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t nwaves = (size_t)gridDim.x * 4;
+    for (size_t c = wave; c < nchunks; c += nwaves) {
+        for (int r0 = 0; r0 < 32; r0 += 8) {
+            if (DEC) {
+                u32x2 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const u32x2* q = (const u32x2*)(src + c * 16384 + (r0 + k) * 512 + lane * 8);
+                    v[k] = NT ? __builtin_nontemporal_load(q) : *q;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    u32x4* q = (u32x4*)(dst + c * 32768 + (r0 + k) * 1024 + lane * 16);
+                    const u32x4 o = {v[k].x, v[k].y, v[k].x ^ 1u, v[k].y ^ 2u};
+                    if (NT) __builtin_nontemporal_store(o, q); else *q = o;
+                }
+            } else {
+                u32x4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const u32x4* q = (const u32x4*)(src + c * 32768 + (r0 + k) * 1024 + lane * 16);
+                    v[k] = NT ? __builtin_nontemporal_load(q) : *q;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    u32x2* q = (u32x2*)(dst + c * 16384 + (r0 + k) * 512 + lane * 8);
+                    const u32x2 o = {v[k].x ^ v[k].z, v[k].y ^ v[k].w};
+                    if (NT) __builtin_nontemporal_store(o, q); else *q = o;
+                }
+            }
+        }
     }
 }
 
@@ -119,7 +164,7 @@ int main(int argc, char** argv) {
         double ms = time_ms([&] { __VA_ARGS__; }, reps);                  \
         printf("%-34s %8.3f ms %8.0f GB/s\n", name, ms, (traffic_gb) / ms * 1e3); \
     }
-    for (int wg_per_cu : {4, 8, 16, 0}) {
+    for (int wg_per_cu : {8, 0}) {
         const unsigned g = wg_per_cu ? (unsigned)(cu * wg_per_cu) : (unsigned)(nvec / (256 * 4));
         printf("-- grid %u (%d workgroups per CU%s)\n", g, wg_per_cu, wg_per_cu ? "" : ": one tile each");
         ROW("copy  K=4 plain", 2 * gb, (k_copy<4, 0, 0><<<g, 256>>>((const u32x4*)src, (u32x4*)dst, nvec)));
@@ -139,6 +184,29 @@ int main(int argc, char** argv) {
             ROW("mix 2 read : 3 written nt", t, (k_mix<2, 3, 1, 1><<<g, 256>>>((const u32x4*)src, (u32x4*)dst, steps)));
             ROW("mix 3 read : 2 written plain", t, (k_mix<3, 2, 0, 0><<<g, 256>>>((const u32x4*)src, (u32x4*)dst, steps)));
             ROW("mix 3 read : 2 written nt", t, (k_mix<3, 2, 1, 1><<<g, 256>>>((const u32x4*)src, (u32x4*)dst, steps)));
+        }
+    }
+    {
+        // the 16-bit side fills one buffer: bytes / 32 KiB chunks, 3 bytes moved per element
+        const size_t nchunks = bytes / 32768;
+        const double t = (double)nchunks * 16384 * 3 / 1e9;
+        for (int wg_per_cu : {2, 6, 0}) {
+            const unsigned g = wg_per_cu ? (unsigned)(cu * wg_per_cu) : (unsigned)(nchunks / 4);
+            printf("-- wavefront per chunk, %d waves per CU (0: one chunk per wavefront, workgroups come and go)\n", wg_per_cu * 4);
+            ROW("decoder-like (1 B in, 2 B out) plain", t, (k_wave_chunks<1, 0><<<g, 256>>>((const uint8_t*)src, (uint8_t*)dst, nchunks)));
+            ROW("decoder-like (1 B in, 2 B out) nt", t, (k_wave_chunks<1, 1><<<g, 256>>>((const uint8_t*)src, (uint8_t*)dst, nchunks)));
+            ROW("encoder-like (2 B in, 1 B out) plain", t, (k_wave_chunks<0, 0><<<g, 256>>>((const uint8_t*)src, (uint8_t*)dst, nchunks)));
+            ROW("encoder-like (2 B in, 1 B out) nt", t, (k_wave_chunks<0, 1><<<g, 256>>>((const uint8_t*)src, (uint8_t*)dst, nchunks)));
+        }
+        const size_t steps = nvec / (256 * 2);
+        const double t2 = (double)steps * 256 * 16 * 3 / 1e9;
+        for (int wg_per_cu : {8, 0}) {
+            const unsigned g = wg_per_cu ? (unsigned)(cu * wg_per_cu) : (unsigned)steps;
+            printf("-- workgroup tiles, grid %u\n", g);
+            ROW("mix 1 read : 2 written plain", t2, (k_mix<1, 2, 0, 0><<<g, 256>>>((const u32x4*)src, (u32x4*)dst, steps)));
+            ROW("mix 1 read : 2 written nt", t2, (k_mix<1, 2, 1, 1><<<g, 256>>>((const u32x4*)src, (u32x4*)dst, steps)));
+            ROW("mix 2 read : 1 written plain", t2, (k_mix<2, 1, 0, 0><<<g, 256>>>((const u32x4*)src, (u32x4*)dst, steps)));
+            ROW("mix 2 read : 1 written nt", t2, (k_mix<2, 1, 1, 1><<<g, 256>>>((const u32x4*)src, (u32x4*)dst, steps)));
         }
     }
     ROW("hipMemcpyDtoD", 2 * gb, CK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, 0)));
