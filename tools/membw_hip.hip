@@ -89,36 +89,36 @@ __global__ __launch_bounds__(256) void k_mix(const u32x4* __restrict__ src, u32x
 // lanes x 16 bytes (16-bit side) or x 8 bytes (byte side) per round, eight rounds in flight.
 // DEC: read the byte side, write the 16-bit side; otherwise the reverse.
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-template <int DEC, int NT>
+template <int DEC, int NT, int B = 8>
 __global__ __launch_bounds__(256) void k_wave_chunks(const uint8_t* __restrict__ src,
                                                      uint8_t* __restrict__ dst, size_t nchunks) {
     const int lane = threadIdx.x & 63;
     const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const size_t nwaves = (size_t)gridDim.x * 4;
     for (size_t c = wave; c < nchunks; c += nwaves) {
-        for (int r0 = 0; r0 < 32; r0 += 8) {
+        for (int r0 = 0; r0 < 32; r0 += B) {
             if (DEC) {
-                u32x2 v[8];
+                u32x2 v[B];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < B; ++k) {
                     const u32x2* q = (const u32x2*)(src + c * 16384 + (r0 + k) * 512 + lane * 8);
                     v[k] = NT ? __builtin_nontemporal_load(q) : *q;
                 }
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < B; ++k) {
                     u32x4* q = (u32x4*)(dst + c * 32768 + (r0 + k) * 1024 + lane * 16);
                     const u32x4 o = {v[k].x, v[k].y, v[k].x ^ 1u, v[k].y ^ 2u};
                     if (NT) __builtin_nontemporal_store(o, q); else *q = o;
                 }
             } else {
-                u32x4 v[8];
+                u32x4 v[B];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < B; ++k) {
                     const u32x4* q = (const u32x4*)(src + c * 32768 + (r0 + k) * 1024 + lane * 16);
                     v[k] = NT ? __builtin_nontemporal_load(q) : *q;
                 }
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < B; ++k) {
                     u32x2* q = (u32x2*)(dst + c * 16384 + (r0 + k) * 512 + lane * 8);
                     const u32x2 o = {v[k].x ^ v[k].z, v[k].y ^ v[k].w};
                     if (NT) __builtin_nontemporal_store(o, q); else *q = o;
@@ -197,6 +197,16 @@ int main(int argc, char** argv) {
             ROW("decoder-like (1 B in, 2 B out) nt", t, (k_wave_chunks<1, 1><<<g, 256>>>((const uint8_t*)src, (uint8_t*)dst, nchunks)));
             ROW("encoder-like (2 B in, 1 B out) plain", t, (k_wave_chunks<0, 0><<<g, 256>>>((const uint8_t*)src, (uint8_t*)dst, nchunks)));
             ROW("encoder-like (2 B in, 1 B out) nt", t, (k_wave_chunks<0, 1><<<g, 256>>>((const uint8_t*)src, (uint8_t*)dst, nchunks)));
+        }
+        {
+            const unsigned g = (unsigned)(cu * 2);
+            printf("-- wavefront per chunk, 8 waves per CU, rounds per burst 2 / 4 / 16 (non-temporal)\n");
+            ROW("encoder-like burst 2", t, (k_wave_chunks<0, 1, 2><<<g, 256>>>((const uint8_t*)src, (uint8_t*)dst, nchunks)));
+            ROW("encoder-like burst 4", t, (k_wave_chunks<0, 1, 4><<<g, 256>>>((const uint8_t*)src, (uint8_t*)dst, nchunks)));
+            ROW("encoder-like burst 16", t, (k_wave_chunks<0, 1, 16><<<g, 256>>>((const uint8_t*)src, (uint8_t*)dst, nchunks)));
+            ROW("decoder-like burst 2", t, (k_wave_chunks<1, 1, 2><<<g, 256>>>((const uint8_t*)src, (uint8_t*)dst, nchunks)));
+            ROW("decoder-like burst 4", t, (k_wave_chunks<1, 1, 4><<<g, 256>>>((const uint8_t*)src, (uint8_t*)dst, nchunks)));
+            ROW("decoder-like burst 16", t, (k_wave_chunks<1, 1, 16><<<g, 256>>>((const uint8_t*)src, (uint8_t*)dst, nchunks)));
         }
         const size_t steps = nvec / (256 * 2);
         const double t2 = (double)steps * 256 * 16 * 3 / 1e9;
