@@ -37,6 +37,16 @@ class hf_entropy_config(C.Structure):
     ]
 
 
+class hf_adaptive_config(C.Structure):
+    _fields_ = [
+        ("encoding_mode", C.c_uint32),
+        ("compression_threshold_q16", C.c_uint32),
+        ("tree_depth_limit", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("min_freq_threshold", C.c_uint64),
+    ]
+
+
 class hf_container_info(C.Structure):
     _fields_ = [
         ("version", C.c_uint32), ("layout", C.c_uint32), ("codebook_kind", C.c_uint32),
@@ -68,6 +78,8 @@ SIGNATURES = {
     "hf_symbol_stat_dev": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, _vp]),
     "hf_symbol_sort": (C.c_int, [_vp, _u64p, C.c_int, _u64p, _u16p]),
     "hf_entropy": (C.c_int, [_vp, _u64p, C.c_int, _u32p, _ip]),
+    "hf_adaptive_threshold": (C.c_int, [C.c_uint32, C.c_int, C.c_int,
+                                        C.POINTER(hf_adaptive_config)]),
     "hf_tree_build": (C.c_int, [_vp, _u64p, C.c_int, C.c_int, _u64p, _u16p, _u16p, _u16p, _u16p]),
     "hf_tree_adjust": (C.c_int, [_vp, _u16p, C.c_int, C.c_int, _u16p]),
     "hf_codebook": (C.c_int, [_vp, _u64p, C.c_int, C.POINTER(hf_entropy_config), _u16p, _u8p]),

@@ -269,6 +269,33 @@ int hf_entropy(hf_ctx* ctx, const uint64_t* h_freq, int N, uint32_t* entropy_q16
     return HF_OK;
 }
 
+int hf_adaptive_threshold(uint32_t entropy_q16, int depth, int wt_width, hf_adaptive_config* out) {
+    if (!out || depth < 2 || depth > 256 || wt_width < 2 || wt_width > 64) return HF_ERR_ARG;
+    // (1 << (wtWidth - 2)) is a Scala Int: the shift count is taken mod 32, and a negative
+    // result cannot become a UInt literal (adaptive_threshold.scala:53 fails to elaborate)
+    const int sh = (wt_width - 2) & 31;
+    if (sh == 31) return HF_ERR_RANGE;
+    const uint32_t dmask = (1u << log2ceil_i(depth)) - 1u;
+    memset(out, 0, sizeof(*out));
+    if (entropy_q16 < 0x8000u) {  // setLowEntropyConfig, :41-46
+        out->encoding_mode = 1;
+        out->compression_threshold_q16 = 19660u;  // (0.3 * 65536).toInt
+        out->tree_depth_limit = (uint32_t)(depth / 4) & dmask;
+        out->min_freq_threshold = 1;
+    } else if (entropy_q16 > 0x60000u) {  // setHighEntropyConfig, :49-54
+        out->encoding_mode = 0;
+        out->compression_threshold_q16 = 58982u;  // (0.9 * 65536).toInt
+        out->tree_depth_limit = (uint32_t)(depth / 8) & dmask;
+        out->min_freq_threshold = (1ull << sh) & mask_w(wt_width);
+    } else {  // setMediumEntropyConfig, :57-62
+        out->encoding_mode = 1;
+        out->compression_threshold_q16 = 39321u;  // (0.6 * 65536).toInt
+        out->tree_depth_limit = (uint32_t)(depth / 2) & dmask;
+        out->min_freq_threshold = 2ull & mask_w(wt_width);
+    }
+    return HF_OK;
+}
+
 /* ---- HuffmanTreeBuilder ---------------------------------------------------------------------- */
 int hf_tree_build(hf_ctx* ctx, const uint64_t* h_freqs, int N, int wt_width, uint64_t* h_weights,
                   uint16_t* h_lefts, uint16_t* h_rights, uint16_t* h_root, uint16_t* h_depths) {

@@ -117,6 +117,22 @@ int hf_symbol_sort(hf_ctx* ctx, const uint64_t* h_freq, int N, uint64_t* h_sorte
 int hf_entropy(hf_ctx* ctx, const uint64_t* h_freq, int N, uint32_t* entropy_q16,
                int* compression_mode);
 
+/* The whole parameter set AdaptiveThreshold keeps in registers for an entropy value
+ * (adaptive_threshold.scala:41-79): the RTL drives only encoding_mode out, the other three sit
+ * behind commented-out ports (:17-22, :82-86).  Values as the registers hold them:
+ * compression_threshold in Q0.16 (0.3 / 0.6 / 0.9), tree_depth_limit = depth/4, depth/2, depth/8
+ * truncated to log2ceil(depth) bits, min_freq_threshold = 1, 2, 2^(wt_width-2) truncated to
+ * wt_width bits, for entropy below 0.5, in between, above 6.0 bits.  Host arithmetic, no
+ * context.  depth in 2..256, wt_width in 2..64. */
+typedef struct hf_adaptive_config {
+    uint32_t encoding_mode;
+    uint32_t compression_threshold_q16;
+    uint32_t tree_depth_limit;
+    uint32_t reserved;
+    uint64_t min_freq_threshold;
+} hf_adaptive_config;
+int hf_adaptive_threshold(uint32_t entropy_q16, int depth, int wt_width, hf_adaptive_config* out);
+
 /* ---- HuffmanTreeBuilder (tree_build.scala:17-140) ----------------------------------------- */
 /* freqs[N] in the caller's index order (the system passes them sorted descending).
  * weights/lefts/rights have 2N-1 entries, entries below N as the RTL initialises them

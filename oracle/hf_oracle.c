@@ -225,6 +225,28 @@ int orc_aw_adaptive_mode(uint32_t e) {
     return 1;
 }
 
+/* adaptive_threshold.scala:41-62: the three register sets, chosen as in :65-79.  Literal
+ * values as Scala computes them: (x * 65536).toInt; depth / k in Int arithmetic, kept in a
+ * log2Ceil(depth)-bit register; 1 << (wtWidth - 2) as an Int shift (count mod 32), kept in a
+ * wtWidth-bit register.  Returns -1 where the Int literal is negative (no such circuit). */
+int orc_aw_adaptive_config(uint32_t e, int depth, int W, uint32_t* mode, uint32_t* thr_q16,
+                           uint32_t* depth_limit, uint64_t* min_freq) {
+    static const double frac[3] = {0.3, 0.6, 0.9};
+    static const int div[3] = {4, 2, 8};
+    const int sel = e < 0x8000u ? 0 : (e > 0x60000u ? 2 : 1); /* low / medium / high */
+    int dbits = 0;
+    while ((1 << dbits) < depth) ++dbits;
+    const int32_t lit = (int32_t)(1u << ((unsigned)(W - 2) % 32u));
+    if (lit < 0) return -1;
+    const uint64_t wmask = W >= 64 ? ~0ull : (1ull << W) - 1ull;
+    const uint64_t mf[3] = {1ull, 2ull, (uint64_t)lit};
+    *mode = sel == 2 ? 0u : 1u;
+    *thr_q16 = (uint32_t)(int)(frac[sel] * 65536.0);
+    *depth_limit = (uint32_t)(depth / div[sel]) & ((1u << dbits) - 1u);
+    *min_freq = mf[sel] & wmask;
+    return 0;
+}
+
 /* entropy_aware_tree_builder.scala:61-66 */
 void orc_aw_filter(const uint64_t* freq, int N, uint64_t thr, uint64_t* out) {
     for (int i = 0; i < N; ++i) out[i] = freq[i] >= thr ? freq[i] : 0;

@@ -67,6 +67,8 @@ def _declare(l: C.CDLL) -> None:
     l.orc_aw_entropy_q16.restype = C.c_uint32
     l.orc_aw_adaptive_mode.argtypes = [C.c_uint32]
     l.orc_aw_adaptive_mode.restype = C.c_int
+    l.orc_aw_adaptive_config.argtypes = [C.c_uint32, C.c_int, C.c_int, _u32p, _u32p, _u32p, _u64p]
+    l.orc_aw_adaptive_config.restype = C.c_int
     l.orc_aw_filter.argtypes = [_u64p, C.c_int, C.c_uint64, _u64p]
     l.orc_aw_filter.restype = None
     l.orc_aw_encode_pairs.argtypes = [_u8p, C.c_size_t, _u16p, _u8p, C.c_int, C.c_int, _u8p]
@@ -180,6 +182,16 @@ def aw_entropy_q16(freq, W: int = 32) -> int:
 
 def aw_adaptive_mode(entropy_q16: int) -> int:
     return int(lib().orc_aw_adaptive_mode(entropy_q16))
+
+
+def aw_adaptive_config(entropy_q16: int, depth: int = 256, W: int = 32):
+    """(mode, compression_threshold_q16, tree_depth_limit, min_freq_threshold), or None where the
+    reference's literal does not elaborate (adaptive_threshold.scala:41-79)."""
+    m, t, d = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    f = C.c_uint64()
+    rc = lib().orc_aw_adaptive_config(entropy_q16, depth, W, C.byref(m), C.byref(t), C.byref(d),
+                                      C.byref(f))
+    return None if rc else (m.value, t.value, d.value, f.value)
 
 
 def aw_filter(freq, thr: int) -> np.ndarray:

@@ -74,6 +74,36 @@ def test_quality_matches_oracle(lib, orc):
     assert rc == -3  # the RTL divides by zero here
 
 
+def test_adaptive_threshold_register_sets(lib, orc):
+    from huffman_amd import api
+    # adaptive_threshold.scala:41-62 at the system's parameters (depth 256, wtWidth 32)
+    at = api.AdaptiveThreshold(256, 32)
+    assert at(0x7FFF) == dict(encoding_mode=1, compression_threshold=19660, tree_depth_limit=64,
+                              min_freq_threshold=1)
+    assert at(0x8000) == dict(encoding_mode=1, compression_threshold=39321, tree_depth_limit=128,
+                              min_freq_threshold=2)
+    assert at(0x60000)["encoding_mode"] == 1
+    assert at(0x60001) == dict(encoding_mode=0, compression_threshold=58982, tree_depth_limit=32,
+                               min_freq_threshold=1 << 30)
+    # every width and depth against the oracle, the mode against the decision the system uses
+    for depth in (2, 4, 16, 100, 256):
+        for W in range(2, 65):
+            for e in (0, 0x7FFF, 0x8000, 0x40000, 0x60000, 0x60001, 0xFFFFFFFF):
+                exp = orc.aw_adaptive_config(e, depth, W)
+                if exp is None:
+                    with pytest.raises(api.HuffhipError):
+                        api.AdaptiveThreshold(depth, W)(e)
+                    continue
+                got = api.AdaptiveThreshold(depth, W)(e)
+                assert tuple(got.values()) == exp, (depth, W, e)
+                assert got["encoding_mode"] == orc.aw_adaptive_mode(e)
+                assert got["min_freq_threshold"] < (1 << W) and got["tree_depth_limit"] < 256
+    cfg = api.L.hf_adaptive_config()
+    assert lib.hf_adaptive_threshold(0, 1, 32, C.byref(cfg)) == -1
+    assert lib.hf_adaptive_threshold(0, 256, 65, C.byref(cfg)) == -1
+    assert lib.hf_adaptive_threshold(0, 256, 32, None) == -1
+
+
 def test_argument_checks_need_no_gpu(lib):
     # null context / null pointers are rejected before any HIP call
     assert lib.hf_flush(None) == -1
