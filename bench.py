@@ -228,6 +228,18 @@ def main():
     nsym_codebook = float(f.sum())  # n * world when the histogram was all-reduced
     lbar = bits_ideal / max(1.0, nsym_codebook)
     comp_bytes = 4 * total_words + n + 4 * (nch + 1) + 256 * 3
+    # TreeQualityAnalyzer (tree_q_analyser.scala:21-47) on this codebook.  Its weighted sum is a
+    # 32-bit wire, so the counts go in shifted right until sum(count x length) fits.
+    fi = freq.cpu().numpy().astype("uint64")
+    qshift = 0
+    while int(((fi >> qshift) * lens.astype("uint64")).sum()) >= (1 << 32):
+        qshift += 1
+    try:
+        q_avg, q_eff, q_ratio = hf.TreeQualityAnalyzer(256, 32, ctx=ctx)(fi >> qshift, lens)
+        quality = {"avg_length_q8": q_avg, "efficiency_q8": q_eff, "compression_ratio_q8": q_ratio,
+                   "counts_shifted_right_by": qshift}
+    except hf.HuffhipError:
+        quality = None
     ratio = 2.0 * n / comp_bytes
 
     raw_bytes = 2.0 * n
@@ -272,6 +284,7 @@ def main():
             "bits_per_exponent_ideal": lbar,
             "bits_per_exponent_stream": 32.0 * total_words / n,
             "compression_mode": mode, "entropy_q16": ent,
+            "tree_quality": quality,
             "roundtrip_bit_exact": ok,
             "roofline": dict(roof[dominant], kernel=dominant),
             "roofline_all": roof,
