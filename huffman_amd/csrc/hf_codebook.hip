@@ -214,8 +214,8 @@ __device__ void stage_tree(CbLds& L, const int N, const int lane) {
 // tree_adjust with its four phases (tree_adjust.scala:44-119) and Kraft-correct moves:
 // BuildHist (depths above lmax clamp to lmax), Migrate (deepest level below lmax gives a leaf
 // to the level under it until the Kraft sum fits), FillHoles (leaves move up while the freed
-// code space allows, deepest level first), Assign (index p takes the smallest depth left).
-// Returns the number of Migrate steps.
+// code space allows, deepest level first), Assign (index p takes the smallest depth left), and
+// with the depths the canonical codes (L.adj and L.code).  Returns the number of Migrate steps.
 template <class LDS>
 __device__ uint32_t stage_adjust(LDS& L, const int N, const int lmax, const int lane) {
     if (lane < 20) L.hist[lane] = 0;
@@ -229,80 +229,70 @@ __device__ uint32_t stage_adjust(LDS& L, const int N, const int lmax, const int 
         }
     }
     __syncthreads();
-    if (lane == 0) {
-        uint32_t kraft = 0;
-        for (int d = 0; d <= lmax; ++d) kraft += L.hist[d] << (lmax - d);
-        const uint32_t full = 1u << lmax;
-        uint32_t steps = 0;
-        while (kraft > full) {
-            int d = lmax - 1;
-            while (d > 0 && L.hist[d] == 0) --d;
-            L.hist[d] -= 1;
-            L.hist[d + 1] += 1;
-            kraft -= 1u << (lmax - d - 1);
-            ++steps;
-        }
-        uint32_t holes = full - kraft;
-        for (int d = lmax; d >= 2; --d) {
-            const uint32_t unit = 1u << (lmax - d);
-            const uint32_t can = holes / unit;
-            const uint32_t mv = L.hist[d] < can ? L.hist[d] : can;
-            L.hist[d] -= mv;
-            L.hist[d - 1] += mv;
-            holes -= mv * unit;
-        }
-        uint32_t c = 0;
-        for (int d = 0; d <= lmax; ++d) {
-            c += L.hist[d];
-            L.cum[d] = c;
-        }
-        L.misc[0] = steps;
+    // The level counts live one per lane from here on (lane d holds level d), the loop control
+    // in scalar registers: no step of Migrate or FillHoles waits for a memory access.
+    uint32_t h = lane <= lmax ? L.hist[lane] : 0u;
+    uint32_t kraft = hf_wave_sum_u32(lane <= lmax ? h << (lmax - lane) : 0u);
+    kraft = (uint32_t)__builtin_amdgcn_readfirstlane((int)kraft);
+    const uint32_t full = 1u << lmax;
+    uint32_t steps = 0;
+    while (kraft > full) {
+        // the deepest level below lmax that still has a leaf (level 0 if none has)
+        const u64 m = __ballot(h != 0 && lane >= 1 && lane < lmax);
+        const int d = m ? 63 - __builtin_clzll(m) : 0;
+        if (lane == d) h -= 1;
+        if (lane == d + 1) h += 1;
+        kraft -= 1u << (lmax - d - 1);
+        ++steps;
     }
-    __syncthreads();
-    // Assign: the depth of index p is the number of levels whose cumulative count is <= p
+    uint32_t holes = full - kraft;
+    for (int d = lmax; d >= 2 && holes != 0; --d) {
+        const uint32_t can = holes >> (lmax - d);  // the freed space in units of a level-d leaf
+        const uint32_t hd = (uint32_t)__builtin_amdgcn_readlane((int)h, d);
+        const uint32_t mv = hd < can ? hd : can;
+        if (lane == d) h -= mv;
+        if (lane == d - 1) h += mv;
+        holes -= mv << (lmax - d);
+    }
+    // cumulative counts, lane d = number of leaves at levels <= d (lanes above lmax repeat N)
+    uint32_t cum = h;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        const uint32_t u = __shfl_up(cum, o);
+        if (lane >= o) cum += u;
+    }
+    // Assign: the depth of index p is the number of levels whose cumulative count is <= p.
+    // Depths therefore never decrease with p, and the canonical code of p follows in the same
+    // pass: count/codeStart as entropy_aware_tree_builder.scala:118-127 (count[0] taken as 0),
+    // code(p) = codeStart[len_p] + #{j < p : len_j == len_p} -- the assignment the RTL's
+    // commented-out loop intends (:105-111) -- where the second term is p minus the number of
+    // leaves on the levels above len_p.
+    uint32_t dep[4] = {0, 0, 0, 0}, above[4] = {0, 0, 0, 0}, start[4] = {0, 0, 0, 0};
+    uint32_t cs = 0;  // codeStart[q] on entry to iteration q
+    for (int q = 0; q <= lmax; ++q) {
+        const uint32_t cq = (uint32_t)__builtin_amdgcn_readlane((int)cum, q);
+        const uint32_t hq = (uint32_t)__builtin_amdgcn_readlane((int)h, q);
+        const uint32_t cs_next = q == 0 ? 0u : ((cs + hq) << 1) & 0xFFFFu;  // codeStart[q + 1]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool in = cq <= (uint32_t)(lane + 64 * i);
+            dep[i] += in;
+            above[i] = in ? cq : above[i];
+            start[i] = in ? cs_next : start[i];
+        }
+        cs = cs_next;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int p = lane + 64 * i;
         if (p < N) {
-            int d = 0;
-            for (int q = 0; q <= lmax; ++q) d += (L.cum[q] <= (uint32_t)p);
-            L.adj[p] = (uint16_t)d;
+            L.adj[p] = (uint16_t)dep[i];
+            L.code[p] = dep[i] ? (uint16_t)(start[i] + (uint32_t)p - above[i]) : (uint16_t)0;
         }
     }
+    if (lane == 0) L.misc[0] = steps;
     __syncthreads();
     return L.misc[0];
-}
-
-// Canonical codes in index order: count/codeStart as entropy_aware_tree_builder.scala:118-127
-// (count[0] forced to 0), code(i) = codeStart[len_i] + #{j < i : len_j == len_i}, the
-// assignment the RTL's commented-out loop intends (:105-111).
-template <class LDS>
-__device__ void stage_canonical(LDS& L, const int N, const int lane) {
-    uint32_t len[4], code[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int e = lane + 64 * i;
-        len[i] = e < N ? L.adj[e] : 0xFFFFu;
-        code[i] = 0;
-    }
-    uint32_t cs = 0, prev_count = 0;
-    for (uint32_t d = 1; d <= 16; ++d) {
-        cs = ((cs + prev_count) << 1) & 0xFFFFu;
-        uint32_t base = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const u64 m = __ballot(len[i] == d);
-            if (len[i] == d) code[i] = (cs + base + hf_mbcnt(m)) & 0xFFFFu;
-            base += (uint32_t)__popcll(m);
-        }
-        prev_count = base;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int e = lane + 64 * i;
-        if (e < N) L.code[e] = (uint16_t)code[i];
-    }
-    __syncthreads();
 }
 
 // ---- module-level stages behind the C ABI's host-table calls ---------------------------------
@@ -338,7 +328,6 @@ __global__ __launch_bounds__(64) void hf_k_stage(hf_stage_io* io, const int N, c
             if (lane == 0) io->root = (uint32_t)(2 * N - 2);
         } else {
             const uint32_t steps = stage_adjust(L, N, lmax, lane);
-            stage_canonical(L, N, lane);
             for (int e = lane; e < N; e += 64) {
                 io->code[e] = L.code[e];
                 io->len[e] = (uint8_t)L.adj[e];
@@ -384,7 +373,6 @@ __global__ __launch_bounds__(64) void hf_k_system(const u64* __restrict__ freq25
         __syncthreads();
         stage_tree(L, N, lane);
         stage_adjust(L, N, HF_MAX_CODE_LEN, lane);
-        stage_canonical(L, N, lane);
         for (int p = lane; p < N; p += 64) {
             const u64 f = sorted[p];
             bits += f * (u64)L.adj[p];
@@ -692,7 +680,6 @@ __global__ __launch_bounds__(64) void hf_k_chunks_back(const uint32_t nbatch, co
         for (int i = 0; i < 4; ++i) L.depth[lane + 64 * i] = (uint16_t)d[i];
         __syncthreads();
         stage_adjust(L, N, HF_MAX_CODE_LEN, lane);
-        stage_canonical(L, N, lane);
         if (mode_req == HF_MODE_BEST) {
             // keep the Huffman table only if it saves bits on this block's own counts
             const uint2 fv = reinterpret_cast<const uint2*>(S.f + (size_t)c * 256)[lane];
@@ -763,7 +750,6 @@ __global__ __launch_bounds__(64) void hf_k_system_chunks_rest(
                 __syncthreads();
                 stage_tree(L, N, lane);
                 stage_adjust(L, N, HF_MAX_CODE_LEN, lane);
-                stage_canonical(L, N, lane);
                 if (mode_req == HF_MODE_BEST) {
                     u64 bits = 0, cnt = 0;
                     for (int p = lane; p < N; p += 64) {
