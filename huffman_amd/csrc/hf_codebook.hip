@@ -211,27 +211,16 @@ __device__ void stage_tree(CbLds& L, const int N, const int lane) {
     __syncthreads();
 }
 
-// tree_adjust with its four phases (tree_adjust.scala:44-119) and Kraft-correct moves:
-// BuildHist (depths above lmax clamp to lmax), Migrate (deepest level below lmax gives a leaf
-// to the level under it until the Kraft sum fits), FillHoles (leaves move up while the freed
-// code space allows, deepest level first), Assign (index p takes the smallest depth left), and
-// with the depths the canonical codes (L.adj and L.code).  Returns the number of Migrate steps.
-template <class LDS>
-__device__ uint32_t stage_adjust(LDS& L, const int N, const int lmax, const int lane) {
-    if (lane < 20) L.hist[lane] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int e = lane + 64 * i;
-        if (e < N) {
-            const int d = L.depth[e] > lmax ? lmax : L.depth[e];
-            atomicAdd(&L.hist[d], 1u);
-        }
-    }
-    __syncthreads();
-    // The level counts live one per lane from here on (lane d holds level d), the loop control
-    // in scalar registers: no step of Migrate or FillHoles waits for a memory access.
-    uint32_t h = lane <= lmax ? L.hist[lane] : 0u;
+// tree_adjust (tree_adjust.scala:44-119) with Kraft-correct moves works on the level counts alone:
+// BuildHist (depths above lmax clamp to lmax) gives the number of leaves per level, Migrate and
+// FillHoles move leaves between levels, Assign hands the levels out by index.  The level counts
+// live one per lane (lane d holds level d) and the loop control in scalar registers, so no step
+// waits for a memory access.
+//
+// Migrate: the deepest level below lmax gives a leaf to the level under it until the Kraft sum
+// fits.  FillHoles: leaves move up while the freed code space allows, deepest level first.
+// Returns the number of Migrate steps.
+__device__ __forceinline__ uint32_t adjust_levels(uint32_t& h, const int lmax, const int lane) {
     uint32_t kraft = hf_wave_sum_u32(lane <= lmax ? h << (lmax - lane) : 0u);
     kraft = (uint32_t)__builtin_amdgcn_readfirstlane((int)kraft);
     const uint32_t full = 1u << lmax;
@@ -254,20 +243,28 @@ __device__ uint32_t stage_adjust(LDS& L, const int N, const int lmax, const int 
         if (lane == d - 1) h += mv;
         holes -= mv << (lmax - d);
     }
-    // cumulative counts, lane d = number of leaves at levels <= d (lanes above lmax repeat N)
+    return steps;
+}
+
+// Assign: the depth of index p is the number of levels whose cumulative count is <= p.  Depths
+// therefore never decrease with p, and the canonical code of p follows in the same pass:
+// count/codeStart as entropy_aware_tree_builder.scala:118-127 (count[0] taken as 0),
+// code(p) = codeStart[len_p] + #{j < p : len_j == len_p} -- the assignment the RTL's
+// commented-out loop intends (:105-111) -- where the second term is p minus the number of leaves
+// on the levels above len_p.  `p` are the four indices this lane handles.
+__device__ __forceinline__ void assign_codes(const uint32_t h, const int lmax, const int lane,
+                                             const uint32_t (&p)[4], uint32_t (&dep)[4],
+                                             uint32_t (&code)[4]) {
+    // cumulative counts, lane d = number of leaves at levels <= d
     uint32_t cum = h;
 #pragma unroll
     for (int o = 1; o < 32; o <<= 1) {
         const uint32_t u = __shfl_up(cum, o);
         if (lane >= o) cum += u;
     }
-    // Assign: the depth of index p is the number of levels whose cumulative count is <= p.
-    // Depths therefore never decrease with p, and the canonical code of p follows in the same
-    // pass: count/codeStart as entropy_aware_tree_builder.scala:118-127 (count[0] taken as 0),
-    // code(p) = codeStart[len_p] + #{j < p : len_j == len_p} -- the assignment the RTL's
-    // commented-out loop intends (:105-111) -- where the second term is p minus the number of
-    // leaves on the levels above len_p.
-    uint32_t dep[4] = {0, 0, 0, 0}, above[4] = {0, 0, 0, 0}, start[4] = {0, 0, 0, 0};
+    uint32_t above[4] = {0, 0, 0, 0}, start[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dep[i] = 0;
     uint32_t cs = 0;  // codeStart[q] on entry to iteration q
     for (int q = 0; q <= lmax; ++q) {
         const uint32_t cq = (uint32_t)__builtin_amdgcn_readlane((int)cum, q);
@@ -275,7 +272,7 @@ __device__ uint32_t stage_adjust(LDS& L, const int N, const int lmax, const int 
         const uint32_t cs_next = q == 0 ? 0u : ((cs + hq) << 1) & 0xFFFFu;  // codeStart[q + 1]
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const bool in = cq <= (uint32_t)(lane + 64 * i);
+            const bool in = cq <= p[i];
             dep[i] += in;
             above[i] = in ? cq : above[i];
             start[i] = in ? cs_next : start[i];
@@ -283,16 +280,38 @@ __device__ uint32_t stage_adjust(LDS& L, const int N, const int lmax, const int 
         cs = cs_next;
     }
 #pragma unroll
+    for (int i = 0; i < 4; ++i) code[i] = dep[i] ? (start[i] + p[i] - above[i]) & 0xFFFFu : 0u;
+}
+
+// The stage over an LDS block: L.depth[N] -> L.adj[N] (limited lengths) and L.code[N].
+template <class LDS>
+__device__ uint32_t stage_adjust(LDS& L, const int N, const int lmax, const int lane) {
+    if (lane < 20) L.hist[lane] = 0;
+    __syncthreads();
+#pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int p = lane + 64 * i;
-        if (p < N) {
-            L.adj[p] = (uint16_t)dep[i];
-            L.code[p] = dep[i] ? (uint16_t)(start[i] + (uint32_t)p - above[i]) : (uint16_t)0;
+        const int e = lane + 64 * i;
+        if (e < N) {
+            const int d = L.depth[e] > lmax ? lmax : L.depth[e];
+            atomicAdd(&L.hist[d], 1u);
         }
     }
-    if (lane == 0) L.misc[0] = steps;
     __syncthreads();
-    return L.misc[0];
+    uint32_t h = lane <= lmax ? L.hist[lane] : 0u;
+    const uint32_t steps = adjust_levels(h, lmax, lane);
+    const uint32_t p[4] = {(uint32_t)lane, (uint32_t)lane + 64u, (uint32_t)lane + 128u,
+                           (uint32_t)lane + 192u};
+    uint32_t dep[4], code[4];
+    assign_codes(h, lmax, lane, p, dep, code);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if ((int)p[i] < N) {
+            L.adj[p[i]] = (uint16_t)dep[i];
+            L.code[p[i]] = (uint16_t)code[i];
+        }
+    }
+    __syncthreads();
+    return steps;
 }
 
 // ---- module-level stages behind the C ABI's host-table calls ---------------------------------
@@ -414,14 +433,14 @@ __global__ __launch_bounds__(64) void hf_k_system(const u64* __restrict__ freq25
 //   merge  one LANE per codebook: the two-queue merge of HuffmanTreeBuilder, which is serial in
 //          nature -- run by one lane of a wavefront it would cost the whole wavefront's issue
 //          slots per codebook, run by 64 lanes on 64 codebooks it costs a 64th of that;
-//   back   one wavefront per codebook: leaf depths, tree_adjust, canonical codes, the record.
-// Between the kernels a codebook lives in a scratch block in global memory (leaf queue, child
-// links, counts in rank order, rank -> symbol, a few words of state).
+//   back   one wavefront per codebook: leaves per level, tree_adjust, canonical codes, the record.
+// Between the kernels a codebook lives in a scratch block in global memory (leaf queue, parent
+// links of the internal nodes, counts in rank order, rank -> symbol, a few words of state).
 constexpr uint32_t kChunkCbTodo = 0xFFFFFFFFu;  // mode word of a record left to the general kernel
 
 struct ChunkScratch {
     uint32_t* lq;     // [batch][256] leaf queue, ascending (weight, rank): weight << 8 | rank
-    uint32_t* child;  // [batch][256] children of internal node N + i: left | right << 16
+    uint8_t* par;     // [batch][256] parent of internal node N + i, as its index minus N
     uint16_t* f;      // [batch][256] counts in rank order
     uint8_t* r2s;     // [batch][256] symbol of rank p
     uint32_t* meta;   // [batch][4]   entropy, mode, total count, 1 if the merge has to run
@@ -432,8 +451,8 @@ ChunkScratch carve_scratch(void* base, const uint64_t batch) {
     ChunkScratch S;
     S.lq = reinterpret_cast<uint32_t*>(p);
     p += batch * 1024;
-    S.child = reinterpret_cast<uint32_t*>(p);
-    p += batch * 1024;
+    S.par = p;
+    p += batch * 256;
     S.f = reinterpret_cast<uint16_t*>(p);
     p += batch * 512;
     S.r2s = p;
@@ -574,7 +593,9 @@ __global__ __launch_bounds__(64) void hf_k_chunks_front(const uint32_t* __restri
 // is preferred on ties).  The leaf queue is read front to back from the scratch block, the queue
 // of internal nodes is a FIFO in LDS (written at node kn, the same index in every lane; read at
 // each lane's own head), the next two candidates of either queue sit in registers so that no
-// memory read is on the decision path, and the child links go to the scratch block.
+// memory read is on the decision path.  What the next stage needs of the tree is the number of
+// leaves per level, and that follows from the parent links of the internal nodes alone (see the
+// back kernel), so those are all that is written.
 __global__ __launch_bounds__(64) void hf_k_chunks_merge(const uint32_t nbatch,
                                                         const ChunkScratch S) {
     constexpr int N = 256;
@@ -583,23 +604,22 @@ __global__ __launch_bounds__(64) void hf_k_chunks_merge(const uint32_t nbatch,
     const uint32_t c = blockIdx.x * 64u + lane;
     if (c >= nbatch || S.meta[c * 4 + 3] == 0) return;
     const uint32_t* lq = S.lq + (size_t)c * 256;
-    uint32_t* child = S.child + (size_t)c * 256;
+    uint8_t* par = S.par + (size_t)c * 256;
     int li = 0, ii = N;
     uint32_t l0 = lq[0], l1 = lq[1];  // the next two leaves (weight << 8 | rank)
     uint32_t iw0 = 0, iw1 = 0;        // w[ii], w[ii + 1] while those nodes exist
     for (int kn = N; kn < 2 * N - 1; ++kn) {
-        uint32_t idx[2], wt[2];
+        uint32_t wt[2];
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const bool leaf = (li < N) && (ii >= kn || (l0 >> 8) <= iw0);
             if (leaf) {
-                idx[p] = l0 & 0xFFu;
                 wt[p] = l0 >> 8;
                 ++li;
                 l0 = l1;
                 l1 = li + 1 < N ? lq[li + 1] : 0u;
             } else {
-                idx[p] = (uint32_t)ii;
+                par[ii - N] = (uint8_t)(kn - N);
                 wt[p] = iw0;
                 ++ii;
                 iw0 = iw1;
@@ -608,29 +628,24 @@ __global__ __launch_bounds__(64) void hf_k_chunks_merge(const uint32_t nbatch,
         }
         const uint32_t ws = wt[0] + wt[1];
         wint[kn - N][lane] = (uint16_t)ws;
-        child[kn - N] = idx[0] | (idx[1] << 16);
         if (ii == kn) iw0 = ws;
         else if (ii + 1 == kn) iw1 = ws;
     }
 }
 
-// LDS of the back kernel
-struct CbLdsBack {
-    uint16_t parent[512];
-    uint16_t depth[256];
-    uint16_t adj[256];
-    uint16_t code[256];
-    uint32_t hist[20];
-    uint32_t cum[20];
-    uint32_t misc[8];
-};
-
-// back: child links -> leaf depths -> tree_adjust -> canonical codes -> the record.
+// back: parent links -> leaves per level -> tree_adjust -> canonical codes -> the record.
+//
+// The internal nodes leave the merge's FIFO in the order they were made, so the parent index never
+// decreases with the node index, and the internal nodes of one level are a contiguous index range
+// directly below the range of the level above (the root alone on level 0).  Level d + 1 is the set
+// of nodes whose parent lies in level d -- one ballot per four nodes -- and a level of I[d]
+// internal nodes under I[d-1] parents leaves 2 I[d-1] - I[d] places to leaves.  tree_adjust needs
+// no more than these counts (clamped to the length limit), so no leaf depth is ever computed.
 __global__ __launch_bounds__(64) void hf_k_chunks_back(const uint32_t nbatch, const int mode_req,
                                                        const ChunkScratch S,
                                                        hf_chunk_cb* __restrict__ cbs) {
     constexpr int N = 256;
-    __shared__ CbLdsBack L;
+    constexpr int lmax = HF_MAX_CODE_LEN;
     const int lane = hf_lane();
     const uint32_t c = blockIdx.x;
     if (c >= nbatch) return;
@@ -641,50 +656,34 @@ __global__ __launch_bounds__(64) void hf_k_chunks_back(const uint32_t nbatch, co
         return;
     }
     const uint32_t ent = S.meta[c * 4 + 0];
+    const uint32_t p[4] = {(uint32_t)lane * 4u, (uint32_t)lane * 4u + 1u, (uint32_t)lane * 4u + 2u,
+                           (uint32_t)lane * 4u + 3u};
+    uint32_t dep[4] = {8, 8, 8, 8}, code[4] = {0, 0, 0, 0};
     if (mode == HF_MODE_HUFFMAN) {
-        // parent links from the child links: node N + k has children child[k]
-        const uint32_t* child = S.child + (size_t)c * 256;
-        if (lane == 0) L.parent[2 * N - 2] = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = lane + 64 * i;
-            if (k < N - 1) {
-                const uint32_t ch = child[k];
-                L.parent[ch & 0xFFFFu] = (uint16_t)(N + k);
-                L.parent[ch >> 16] = (uint16_t)(N + k);
-            }
-        }
-        __syncthreads();
-        // true leaf depth = number of parent links up to the root; the four climbs of a lane
-        // advance together so that their LDS reads overlap
-        const int root = 2 * N - 2;
-        int pp[4], d[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            pp[i] = lane + 64 * i;
-            d[i] = 0;
-        }
-        for (;;) {
-            bool more = false;
+        // lane l holds the parents of internal nodes 4l .. 4l+3 (node N-2 is the root, N-1 no node)
+        const uint32_t par4 = reinterpret_cast<const uint32_t*>(S.par + (size_t)c * 256)[lane];
+        uint32_t lo = N - 2, hi = N - 2, up = 1;  // the level above: index range and size
+        uint32_t h = 0;                           // leaves on level `lane`
+        for (uint32_t d = 1;; ++d) {
+            uint32_t cnt = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (pp[i] != root) {
-                    pp[i] = L.parent[pp[i]];
-                    ++d[i];
-                    more = true;
-                }
+                const uint32_t pk = (par4 >> (8 * i)) & 0xFFu;
+                cnt += (uint32_t)__popcll(__ballot(p[i] < (uint32_t)(N - 2) && pk >= lo && pk <= hi));
             }
-            if (!__any(more)) break;
+            if ((uint32_t)lane == (d < (uint32_t)lmax ? d : (uint32_t)lmax)) h += 2u * up - cnt;
+            if (cnt == 0) break;
+            hi = lo - 1u;
+            lo -= cnt;
+            up = cnt;
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) L.depth[lane + 64 * i] = (uint16_t)d[i];
-        __syncthreads();
-        stage_adjust(L, N, HF_MAX_CODE_LEN, lane);
+        adjust_levels(h, lmax, lane);
+        assign_codes(h, lmax, lane, p, dep, code);
         if (mode_req == HF_MODE_BEST) {
             // keep the Huffman table only if it saves bits on this block's own counts
             const uint2 fv = reinterpret_cast<const uint2*>(S.f + (size_t)c * 256)[lane];
-            uint32_t bits = (fv.x & 0xFFFFu) * L.adj[lane * 4] + (fv.x >> 16) * L.adj[lane * 4 + 1] +
-                            (fv.y & 0xFFFFu) * L.adj[lane * 4 + 2] + (fv.y >> 16) * L.adj[lane * 4 + 3];
+            uint32_t bits = (fv.x & 0xFFFFu) * dep[0] + (fv.x >> 16) * dep[1] +
+                            (fv.y & 0xFFFFu) * dep[2] + (fv.y >> 16) * dep[3];
             bits = hf_wave_sum_u32(bits);
             if (bits >= 8u * S.meta[c * 4 + 2]) mode = HF_MODE_BYPASS;
         }
@@ -701,9 +700,8 @@ __global__ __launch_bounds__(64) void hf_k_chunks_back(const uint32_t nbatch, co
         uint32_t len4 = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int p = lane * 4 + i;
-            const uint32_t sym = (r2s4 >> (8 * i)) & 0xFFu, len = L.adj[p];
-            cb->enc[sym] = (uint32_t)L.code[p] | (len << 16);
+            const uint32_t sym = (r2s4 >> (8 * i)) & 0xFFu, len = dep[i];
+            cb->enc[sym] = code[i] | (len << 16);
             len4 |= len << (8 * i);
         }
         reinterpret_cast<uint32_t*>(cb->rank2sym)[lane] = r2s4;
@@ -893,7 +891,7 @@ void hf_launch_system(const unsigned long long* d_freq256, int mode, unsigned lo
     hipLaunchKernelGGL(hf_k_system, dim3(1), dim3(64), 0, s, d_freq256, mode, thr, cb);
 }
 
-size_t hf_chunk_cb_scratch_bytes(void) { return (size_t)HF_CB_BATCH * (1024 + 1024 + 512 + 256 + 16); }
+size_t hf_chunk_cb_scratch_bytes(void) { return (size_t)HF_CB_BATCH * (1024 + 256 + 512 + 256 + 16); }
 
 void hf_launch_system_chunks(const uint32_t* d_freq_chunks, uint64_t nchunks, int mode,
                              unsigned long long thr, hf_chunk_cb* cbs, void* d_scratch,
