@@ -431,3 +431,33 @@ def test_large_bf16_stream_properties(hf):
     out = hf.ParrallelHuffmanDecoder().decode(s)
     assert torch.equal(out.view(torch.int16), w.view(torch.int16))
     assert 1.4 < s.ratio() < 1.6
+
+
+def test_config2_full_size_properties(hf):
+    # the headline workload itself: 8 030 261 248 bf16 elements (16.06 GB), one codebook, forced
+    # Huffman.  The oracle cannot follow at this size; what must hold at any size is checked:
+    # exact round trip, chunk offsets strictly increasing and ending at the total, payload bits =
+    # sum(count x length) + bounded look-ahead, the histogram summing to n, a prefix code.
+    import bench
+    n = bench.LLAMA3_8B_PARAMS
+    if torch.cuda.get_device_properties(0).total_memory < 80e9:
+        pytest.skip("needs ~50 GB of device memory")
+    w = bench.make_weights(torch, n, DEV)
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    freq = sys_.histogram(w).cpu().numpy()
+    assert int(freq.sum()) == n
+    s = sys_.encode(w, mode=hf.HF_MODE_HUFFMAN)
+    nch = (n + 16383) // 16384
+    off = s.chunk_off[: nch + 1].cpu().numpy().view(np.uint32).astype(np.int64)
+    assert off[0] == 0 and off[-1] == s.total_words and np.all(np.diff(off) > 0)
+    code, lens, mode, _ = s.codebook.download()
+    assert mode == 1 and lens.max() <= 16 and abs(kraft(lens) - 1.0) < 1e-12
+    ideal_bits = float((freq.astype(np.float64) * lens).sum())
+    assert ideal_bits <= 32.0 * s.total_words <= ideal_bits + nch * 64 * 96
+    # the side stream is the sign and mantissa of every element
+    probe = slice(n - 100000, n)
+    wv = w[probe].view(torch.int16).to(torch.int32) & 0xFFFF
+    assert torch.equal(s.side[probe].to(torch.int32), ((wv >> 8) & 0x80) | (wv & 0x7F))
+    out = hf.ParrallelHuffmanDecoder().decode(s)
+    assert torch.equal(out.view(torch.int16), w.view(torch.int16))
+    assert 1.45 < s.ratio() < 1.52
