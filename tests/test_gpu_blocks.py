@@ -207,3 +207,39 @@ def test_best_mode_keeps_huffman_only_where_it_pays(hf, orc):
         if mode == 1:
             assert np.array_equal(code, ecode) and np.array_equal(lens, elens)
         assert torch.equal(hf.ParrallelHuffmanDecoder().decode(st), d)
+
+
+def test_config3_full_size(hf, orc):
+    # 2^18 fp8 pages (4 GiB), one codebook per page: the codebook kernels go through their scratch
+    # block in four batches.  Round trip and decode-on-read at full size; pages on either side of
+    # every batch boundary against the oracle.
+    n_pages = 1 << 18
+    g = torch.Generator(device=DEV).manual_seed(7)
+    scale = torch.exp(torch.randn(1024, generator=g, device=DEV) * 0.7)
+    t = torch.empty(n_pages * CH, dtype=torch.uint8, device=DEV)
+    step = 1 << 14
+    for lo in range(0, n_pages, step):
+        x = torch.randn(step * 16, 1024, generator=g, device=DEV) * scale
+        t[lo * CH:(lo + step) * CH] = x.to(torch.float8_e4m3fn).view(torch.uint8).reshape(-1)
+        del x
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    s = sys_.encode_blocks(t, mode=hf.HF_MODE_HUFFMAN)
+    off = s.chunk_off[: n_pages + 1].cpu().numpy().view(np.uint32).astype(np.int64)
+    assert off[0] == 0 and off[-1] == s.total_words and np.all(np.diff(off) > 0)
+    for c in (0, 1, 65535, 65536, 131071, 131072, 196607, 196608, n_pages - 1):
+        blk = t[c * CH:(c + 1) * CH].cpu().numpy()
+        f = orc.aw_symbol_stat(blk, 256, 32)
+        code, lens = orc.rp_system_codebook(f, 64, 0, 16)
+        gc, gl, m, ent = sys_.block_codebook(s, c)
+        assert m == 1 and ent == orc.rp_entropy_q16_u64(f)
+        assert np.array_equal(gc, code) and np.array_equal(gl, lens), c
+        p, _ = orc.rp_encode(blk, code, lens)
+        got = s.payload[int(off[c]):int(off[c + 1])].cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, p), c
+    out = hf.ParrallelHuffmanDecoder().decode(s)
+    assert torch.equal(out, t)
+    del out
+    ids = torch.randperm(n_pages, device=DEV)[:4096].to(torch.int32)
+    part = hf.ParrallelHuffmanDecoder().decode_blocks(s, chunk_ids=ids)
+    assert torch.equal(part, t.view(n_pages, CH)[ids.long()].reshape(-1))
+    assert 1.05 < s.ratio() < 1.3
