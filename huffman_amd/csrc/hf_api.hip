@@ -424,6 +424,7 @@ int hf_encode_pairs(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
                     const void* d_codebook, hf_code_beat* d_beats) {
     if (!ctx || !d_codebook || !layout_ok(layout) || (n && (!d_data || !d_beats)))
         return HF_ERR_ARG;
+    if (!aligned16(d_data) || !aligned16(d_beats) || !aligned16(d_codebook)) return HF_ERR_ALIGN;
     if (int rc = use_device(ctx)) return rc;
     hf_launch_pairs(d_data, n, norm_layout(layout), reinterpret_cast<const hf_cb_dev*>(d_codebook),
                     d_beats, ctx->stream);

@@ -863,19 +863,51 @@ __global__ __launch_bounds__(256) void hf_k_pairs(const void* __restrict__ data,
     enc[threadIdx.x] = cb->enc[threadIdx.x];
     const uint32_t mode = cb->mode;
     __syncthreads();
+    // a beat is {code u16, length u8, mode u8} = the encoder table entry with the mode on top;
+    // a lane takes 4 consecutive symbols and writes their 4 beats as one 16-byte store, so both
+    // the loads and the stores of a wavefront are contiguous; two such groups per iteration
+    static_assert(sizeof(hf_code_beat) == 4, "beat layout");
+    const uint32_t mtop = mode << 24;
+    const uint64_t ngroups = n / 8 * 2;  // groups of 4 symbols (the last n % 8 symbols go below)
     const uint64_t stride = (uint64_t)gridDim.x * 256;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        uint32_t s;
+    uint32_t* o32 = reinterpret_cast<uint32_t*>(out);
+    auto load4 = [&](const uint64_t g, uint32_t (&sy)[4]) {
+        if (LAYOUT == HF_LAYOUT_BF16_EXP) {
+            const hf_u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const hf_u32x2*>(data) + g);
+            sy[0] = (v.x >> 7) & 0xFFu, sy[1] = (v.x >> 23) & 0xFFu;
+            sy[2] = (v.y >> 7) & 0xFFu, sy[3] = (v.y >> 23) & 0xFFu;
+        } else {
+            const uint32_t v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(data) + g);
+            sy[0] = v & 0xFFu, sy[1] = (v >> 8) & 0xFFu, sy[2] = (v >> 16) & 0xFFu, sy[3] = v >> 24;
+        }
+    };
+    auto store4 = [&](const uint64_t g, const uint32_t (&sy)[4]) {
+        __builtin_nontemporal_store(hf_u32x4{enc[sy[0]] | mtop, enc[sy[1]] | mtop, enc[sy[2]] | mtop,
+                                             enc[sy[3]] | mtop},
+                                    reinterpret_cast<hf_u32x4*>(o32) + g);
+    };
+    uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; g + stride < ngroups; g += 2 * stride) {
+        uint32_t a[4], b[4];
+        load4(g, a);
+        load4(g + stride, b);
+        store4(g, a);
+        store4(g + stride, b);
+    }
+    if (g < ngroups) {
+        uint32_t a[4];
+        load4(g, a);
+        store4(g, a);
+    }
+    // the last n % 8 symbols
+    if (blockIdx.x == 0 && threadIdx.x < (uint32_t)(n - ngroups * 4)) {
+        const uint64_t i = ngroups * 4 + threadIdx.x;
+        uint32_t sym;
         if (LAYOUT == HF_LAYOUT_BF16_EXP)
-            s = (reinterpret_cast<const uint16_t*>(data)[i] >> 7) & 0xFFu;
+            sym = (reinterpret_cast<const uint16_t*>(data)[i] >> 7) & 0xFFu;
         else
-            s = reinterpret_cast<const uint8_t*>(data)[i];
-        const uint32_t e = enc[s];
-        hf_code_beat b;
-        b.code = (uint16_t)(e & 0xFFFFu);
-        b.length = (uint8_t)(e >> 16);
-        b.compression_mode = (uint8_t)mode;
-        out[i] = b;
+            sym = reinterpret_cast<const uint8_t*>(data)[i];
+        o32[i] = enc[sym] | mtop;
     }
 }
 
@@ -919,8 +951,9 @@ void hf_launch_tables(hf_cb_dev* cb, hipStream_t s) {
 void hf_launch_pairs(const void* d_data, uint64_t n, int layout, const hf_cb_dev* cb,
                      hf_code_beat* out, hipStream_t s) {
     if (n == 0) return;
-    uint64_t grid = (n + 255) / 256;
-    if (grid > 2048) grid = 2048;
+    uint64_t grid = (n / 8 + 255) / 256;  // two 4-symbol groups per thread and pass
+    if (grid > 8192) grid = 8192;
+    if (grid == 0) grid = 1;
     if (layout == HF_LAYOUT_BF16_EXP)
         hipLaunchKernelGGL(hf_k_pairs<HF_LAYOUT_BF16_EXP>, dim3((unsigned)grid), dim3(256), 0, s,
                            d_data, n, cb, out);

@@ -306,8 +306,9 @@ def test_bypass_and_auto_modes(hf, orc):
         system_roundtrip(hf, orc, dev_u8(sym), sym, mode=hf.HF_MODE_AUTO)
 
 
-def test_encode_pairs_vs_oracle(hf, orc):
-    sym = skewed_symbols(10000, 8, "geometric")
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 10000, 10007, (1 << 20) + 5])
+def test_encode_pairs_vs_oracle(hf, orc, n):
+    sym = skewed_symbols(n, 8, "geometric")
     d = dev_u8(sym)
     sys_ = hf.EntropyAwareHuffmanSystem()
     for mode in (hf.HF_MODE_HUFFMAN, hf.HF_MODE_BYPASS):
@@ -317,6 +318,19 @@ def test_encode_pairs_vs_oracle(hf, orc):
         exp = orc.aw_encode_pairs(sym, code, lens, m, 8)
         assert np.array_equal(beats[:, 0], exp[:, 0].astype(np.uint32) | (exp[:, 1].astype(np.uint32) << 8))
         assert np.array_equal(beats[:, 1], exp[:, 2]) and np.array_equal(beats[:, 2], exp[:, 3])
+
+
+def test_encode_pairs_bf16_vs_oracle(hf, orc):
+    w = gaussian_bf16(100003, seed=12)
+    sym, _ = orc.symbolize(w, orc.LAYOUT_BF16_EXP)
+    d = dev_bf16(w)
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    cb = sys_.codebook(sys_.histogram(d), hf.HF_MODE_HUFFMAN)
+    code, lens, m, _ = cb.download()
+    beats = sys_.encode_pairs(d, cb)
+    exp = orc.aw_encode_pairs(sym, code, lens, m, 8)
+    assert np.array_equal(beats[:, 0], exp[:, 0].astype(np.uint32) | (exp[:, 1].astype(np.uint32) << 8))
+    assert np.array_equal(beats[:, 1], exp[:, 2]) and np.array_equal(beats[:, 2], exp[:, 3])
 
 
 def test_memwrapper_uploaded_codebook(hf, orc):
