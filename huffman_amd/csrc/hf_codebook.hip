@@ -429,17 +429,16 @@ __global__ __launch_bounds__(64) void hf_k_system(const u64* __restrict__ freq25
 
 // ---- per-block codebooks ----------------------------------------------------------------------
 // A batch of per-block codebooks goes through three kernels, each parallel the way its phase is:
-//   front  one wavefront per codebook: SymbolSort, ShannonEntropy, mode, sFilter, leaf queue;
+//   front  one wavefront per codebook: SymbolSort, ShannonEntropy, mode;
 //   merge  one LANE per codebook: the two-queue merge of HuffmanTreeBuilder, which is serial in
 //          nature -- run by one lane of a wavefront it would cost the whole wavefront's issue
 //          slots per codebook, run by 64 lanes on 64 codebooks it costs a 64th of that;
 //   back   one wavefront per codebook: leaves per level, tree_adjust, canonical codes, the record.
-// Between the kernels a codebook lives in a scratch block in global memory (leaf queue, parent
-// links of the internal nodes, counts in rank order, rank -> symbol, a few words of state).
+// Between the kernels a codebook lives in a scratch block in global memory (counts in rank
+// order, rank -> symbol, parent links of the internal nodes, a few words of state).
 constexpr uint32_t kChunkCbTodo = 0xFFFFFFFFu;  // mode word of a record left to the general kernel
 
 struct ChunkScratch {
-    uint32_t* lq;     // [batch][256] leaf queue, ascending (weight, rank): weight << 8 | rank
     uint8_t* par;     // [batch][256] parent of internal node N + i, as its index minus N
     uint16_t* f;      // [batch][256] counts in rank order
     uint8_t* r2s;     // [batch][256] symbol of rank p
@@ -449,8 +448,6 @@ struct ChunkScratch {
 ChunkScratch carve_scratch(void* base, const uint64_t batch) {
     uint8_t* p = reinterpret_cast<uint8_t*>(base);
     ChunkScratch S;
-    S.lq = reinterpret_cast<uint32_t*>(p);
-    p += batch * 1024;
     S.par = p;
     p += batch * 256;
     S.f = reinterpret_cast<uint16_t*>(p);
@@ -461,33 +458,11 @@ ChunkScratch carve_scratch(void* base, const uint64_t batch) {
     return S;
 }
 
-// Inclusive max-scan / min-scan helpers over the 64 lanes.
-__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v, const int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t u = __shfl_up(v, o);
-        if (lane >= o) v = v > u ? v : u;
-    }
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_incl_min_from_right(uint32_t v, const int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t u = __shfl_down(v, o);
-        if (lane + o < 64) v = v < u ? v : u;
-    }
-    return v;
-}
-
-// front: counts of one block -> sorted order, entropy, mode, leaf queue.  32-bit keys and weights
+// front: counts of one block -> counts and symbols in rank order, entropy, mode.  32-bit keys
 // (counts of a real block sum to 16384; sums of 2^16 and more are left to the general kernel).
-// The leaf queue is read off the sorted order instead of being sorted again: leaves in rank order
-// have non-increasing weights, so the queue position of rank e is (#leaves lighter than e) +
-// (e's place in its run of equal weights), and both follow from the run boundaries.
 __global__ __launch_bounds__(64) void hf_k_chunks_front(const uint32_t* __restrict__ freq_chunks,
                                                         const uint32_t nbatch, const int mode_req,
-                                                        const u64 thr, const ChunkScratch S) {
-    constexpr int N = 256;
+                                                        const ChunkScratch S) {
     const int lane = hf_lane();
     const uint32_t c = blockIdx.x;
     if (c >= nbatch) return;
@@ -546,88 +521,75 @@ __global__ __launch_bounds__(64) void hf_k_chunks_front(const uint32_t* __restri
         S.meta[c * 4 + 2] = tot;
         S.meta[c * 4 + 3] = mode == HF_MODE_HUFFMAN;
     }
-    if (mode != HF_MODE_HUFFMAN) return;  // wave-uniform
-    // sFilter (entropy_aware_tree_builder.scala:61-66)
-    uint32_t wf[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) wf[i] = (u64)f[i] < thr ? 0u : f[i];
-    const uint32_t prev_last = __shfl_up(wf[3], 1);
-    bool b[4];
-    b[0] = lane == 0 || wf[0] != prev_last;
-#pragma unroll
-    for (int i = 1; i < 4; ++i) b[i] = wf[i] != wf[i - 1];
-    // start of the run containing e: the last boundary at or before e
-    uint32_t last_b = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (b[i]) last_b = (uint32_t)(lane * 4 + i);
-    const uint32_t incl = wave_incl_max(last_b, lane);
-    uint32_t carry = __shfl_up(incl, 1);
-    if (lane == 0) carry = 0;
-    uint32_t rs[4];
-    uint32_t cur = carry;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (b[i]) cur = (uint32_t)(lane * 4 + i);
-        rs[i] = cur;
-    }
-    // end of the run (exclusive): the first boundary after e, or N
-    uint32_t first_b = N;
-#pragma unroll
-    for (int i = 3; i >= 0; --i)
-        if (b[i]) first_b = (uint32_t)(lane * 4 + i);
-    const uint32_t incr = wave_incl_min_from_right(first_b, lane);
-    uint32_t nxt = __shfl_down(incr, 1);
-    if (lane == 63) nxt = N;
-    uint32_t* lq = S.lq + (size_t)c * 256;
-#pragma unroll
-    for (int i = 3; i >= 0; --i) {
-        const uint32_t e = (uint32_t)(lane * 4 + i);
-        const uint32_t pos = (N - nxt) + (e - rs[i]);
-        lq[pos] = (wf[i] << 8) | e;
-        if (b[i]) nxt = e;
-    }
 }
 
 // merge: lane = codebook.  HuffmanTreeBuilder as a two-queue merge (see stage_tree; the leaf queue
-// is preferred on ties).  The leaf queue is read front to back from the scratch block, the queue
-// of internal nodes is a FIFO in LDS (written at node kn, the same index in every lane; read at
-// each lane's own head), the next two candidates of either queue sit in registers so that no
-// memory read is on the decision path.  What the next stage needs of the tree is the number of
-// leaves per level, and that follows from the parent links of the internal nodes alone (see the
-// back kernel), so those are all that is written.
-__global__ __launch_bounds__(64) void hf_k_chunks_merge(const uint32_t nbatch,
+// is preferred on ties).  Only weights matter here: what the next stage needs of the tree is the
+// number of leaves per level, and that follows from the parent links of the internal nodes alone
+// (see the back kernel).  The leaf queue is therefore just the counts in rank order read backwards
+// (sFilter applied: entropy_aware_tree_builder.scala:61-66), whatever order ties would take.
+// Both queues live in LDS, one column per lane: the 64 rank-ordered count arrays are loaded with
+// coalesced reads and transposed on the way in (rows padded to 66 entries so that the transposing
+// writes spread over 8 banks), the queue of internal nodes is a FIFO written at node kn, the same
+// row in every lane, and read at each lane's own head; it reuses the rows of the leaves already
+// taken, so a wavefront needs 33 KiB and four of them fit a CU.  The next two candidates of either queue
+// sit in registers, fetched one pick before they can become a head.
+constexpr int kLqStride = 66;
+__global__ __launch_bounds__(64) void hf_k_chunks_merge(const uint32_t nbatch, const u64 thr,
                                                         const ChunkScratch S) {
     constexpr int N = 256;
-    __shared__ uint16_t wint[N][64];  // weight of internal node N + i, per lane
+    // Row q holds leaf weight q of the ascending queue (rank N - 1 - q) until the lane has taken
+    // it, afterwards the weight of internal node N + q: node N + q is made when at least q leaves
+    // are gone (every merge takes two nodes and at most q internal ones exist to take), and the
+    // leaves q and q + 1 already sit in registers by then.
+    __shared__ uint16_t lqw[N][kLqStride];
     const int lane = hf_lane();
-    const uint32_t c = blockIdx.x * 64u + lane;
+    const uint32_t c0 = blockIdx.x * 64u;
+    {
+        const uint32_t nhere = nbatch - c0 < 64u ? nbatch - c0 : 64u;
+        for (uint32_t j0 = 0; j0 < nhere; j0 += 8) {
+            uint2 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                v[k] = j0 + k < nhere
+                           ? reinterpret_cast<const uint2*>(S.f + (size_t)(c0 + j0 + k) * 256)[lane]
+                           : make_uint2(0u, 0u);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t w4[4] = {v[k].x & 0xFFFFu, v[k].x >> 16, v[k].y & 0xFFFFu, v[k].y >> 16};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    lqw[N - 1 - (lane * 4 + i)][j0 + k] = (u64)w4[i] < thr ? (uint16_t)0 : (uint16_t)w4[i];
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t c = c0 + lane;
     if (c >= nbatch || S.meta[c * 4 + 3] == 0) return;
-    const uint32_t* lq = S.lq + (size_t)c * 256;
     uint8_t* par = S.par + (size_t)c * 256;
     int li = 0, ii = N;
-    uint32_t l0 = lq[0], l1 = lq[1];  // the next two leaves (weight << 8 | rank)
-    uint32_t iw0 = 0, iw1 = 0;        // w[ii], w[ii + 1] while those nodes exist
+    uint32_t l0 = lqw[0][lane], l1 = lqw[1][lane];  // the next two leaf weights
+    uint32_t iw0 = 0, iw1 = 0;                      // w[ii], w[ii + 1] while those nodes exist
     for (int kn = N; kn < 2 * N - 1; ++kn) {
         uint32_t wt[2];
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            const bool leaf = (li < N) && (ii >= kn || (l0 >> 8) <= iw0);
+            const bool leaf = (li < N) && (ii >= kn || l0 <= iw0);
             if (leaf) {
-                wt[p] = l0 >> 8;
+                wt[p] = l0;
                 ++li;
                 l0 = l1;
-                l1 = li + 1 < N ? lq[li + 1] : 0u;
+                l1 = li + 1 < N ? (uint32_t)lqw[li + 1][lane] : 0u;
             } else {
                 par[ii - N] = (uint8_t)(kn - N);
                 wt[p] = iw0;
                 ++ii;
                 iw0 = iw1;
-                iw1 = ii + 1 < kn ? (uint32_t)wint[ii + 1 - N][lane] : 0u;
+                iw1 = ii + 1 < kn ? (uint32_t)lqw[ii + 1 - N][lane] : 0u;
             }
         }
         const uint32_t ws = wt[0] + wt[1];
-        wint[kn - N][lane] = (uint16_t)ws;
+        lqw[kn - N][lane] = (uint16_t)ws;
         if (ii == kn) iw0 = ws;
         else if (ii + 1 == kn) iw1 = ws;
     }
@@ -923,7 +885,7 @@ void hf_launch_system(const unsigned long long* d_freq256, int mode, unsigned lo
     hipLaunchKernelGGL(hf_k_system, dim3(1), dim3(64), 0, s, d_freq256, mode, thr, cb);
 }
 
-size_t hf_chunk_cb_scratch_bytes(void) { return (size_t)HF_CB_BATCH * (1024 + 256 + 512 + 256 + 16); }
+size_t hf_chunk_cb_scratch_bytes(void) { return (size_t)HF_CB_BATCH * (256 + 512 + 256 + 16); }
 
 void hf_launch_system_chunks(const uint32_t* d_freq_chunks, uint64_t nchunks, int mode,
                              unsigned long long thr, hf_chunk_cb* cbs, void* d_scratch,
@@ -934,8 +896,8 @@ void hf_launch_system_chunks(const uint32_t* d_freq_chunks, uint64_t nchunks, in
     for (uint64_t c0 = 0; c0 < nchunks; c0 += HF_CB_BATCH) {
         const uint32_t nb = (uint32_t)(nchunks - c0 < HF_CB_BATCH ? nchunks - c0 : HF_CB_BATCH);
         hipLaunchKernelGGL(hf_k_chunks_front, dim3(nb), dim3(64), 0, s, d_freq_chunks + c0 * 256, nb,
-                           mode, thr, S);
-        hipLaunchKernelGGL(hf_k_chunks_merge, dim3((nb + 63) / 64), dim3(64), 0, s, nb, S);
+                           mode, S);
+        hipLaunchKernelGGL(hf_k_chunks_merge, dim3((nb + 63) / 64), dim3(64), 0, s, nb, thr, S);
         hipLaunchKernelGGL(hf_k_chunks_back, dim3(nb), dim3(64), 0, s, nb, mode, S, cbs + c0);
     }
     uint64_t rest = (nchunks + 63) / 64;
