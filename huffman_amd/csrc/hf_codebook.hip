@@ -532,7 +532,8 @@ __global__ __launch_bounds__(64) void hf_k_chunks_front(const uint32_t* __restri
 // coalesced reads and transposed on the way in (rows padded to 66 entries so that the transposing
 // writes spread over 8 banks), the queue of internal nodes is a FIFO written at node kn, the same
 // row in every lane, and read at each lane's own head; it reuses the rows of the leaves already
-// taken, so a wavefront needs 33 KiB and four of them fit a CU.  The next two candidates of either queue
+// taken, so a wavefront needs 33 KiB and four of them fit a CU.  A node that leaves the FIFO
+// leaves its cell to the index of its parent, and the parent links go out coalesced at the end.  The next two candidates of either queue
 // sit in registers, fetched one pick before they can become a head.
 constexpr int kLqStride = 66;
 __global__ __launch_bounds__(64) void hf_k_chunks_merge(const uint32_t nbatch, const u64 thr,
@@ -565,12 +566,11 @@ __global__ __launch_bounds__(64) void hf_k_chunks_merge(const uint32_t nbatch, c
     }
     __syncthreads();
     const uint32_t c = c0 + lane;
-    if (c >= nbatch || S.meta[c * 4 + 3] == 0) return;
-    uint8_t* par = S.par + (size_t)c * 256;
+    const bool run = c < nbatch && S.meta[c * 4 + 3] != 0;
     int li = 0, ii = N;
     uint32_t l0 = lqw[0][lane], l1 = lqw[1][lane];  // the next two leaf weights
     uint32_t iw0 = 0, iw1 = 0;                      // w[ii], w[ii + 1] while those nodes exist
-    for (int kn = N; kn < 2 * N - 1; ++kn) {
+    for (int kn = N; run && kn < 2 * N - 1; ++kn) {
         uint32_t wt[2];
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -581,7 +581,8 @@ __global__ __launch_bounds__(64) void hf_k_chunks_merge(const uint32_t nbatch, c
                 l0 = l1;
                 l1 = li + 1 < N ? (uint32_t)lqw[li + 1][lane] : 0u;
             } else {
-                par[ii - N] = (uint8_t)(kn - N);
+                // the node's weight is in a register by now: its cell takes the parent's index
+                lqw[ii - N][lane] = (uint16_t)(kn - N);
                 wt[p] = iw0;
                 ++ii;
                 iw0 = iw1;
@@ -592,6 +593,16 @@ __global__ __launch_bounds__(64) void hf_k_chunks_merge(const uint32_t nbatch, c
         lqw[kn - N][lane] = (uint16_t)ws;
         if (ii == kn) iw0 = ws;
         else if (ii + 1 == kn) iw1 = ws;
+    }
+    __syncthreads();
+    // parent links out, transposed back: lane l writes the parents of nodes 4l .. 4l+3 of one
+    // codebook after the other (row N - 2 is the root's weight, row N - 1 unused: never read)
+    const uint32_t nhere = nbatch - c0 < 64u ? nbatch - c0 : 64u;
+    for (uint32_t j = 0; j < nhere; ++j) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v |= ((uint32_t)lqw[lane * 4 + i][j] & 0xFFu) << (8 * i);
+        reinterpret_cast<uint32_t*>(S.par + (size_t)(c0 + j) * 256)[lane] = v;
     }
 }
 
