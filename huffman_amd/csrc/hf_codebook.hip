@@ -229,10 +229,25 @@ __device__ __forceinline__ uint32_t adjust_levels(uint32_t& h, const int lmax, c
         // the deepest level below lmax that still has a leaf (level 0 if none has)
         const u64 m = __ballot(h != 0 && lane >= 1 && lane < lmax);
         const int d = m ? 63 - __builtin_clzll(m) : 0;
-        if (lane == d) h -= 1;
-        if (lane == d + 1) h += 1;
-        kraft -= 1u << (lmax - d - 1);
-        ++steps;
+        // A leaf that leaves level d is, step after step, the deepest leaf below lmax again and
+        // walks down to lmax: lmax - d steps that take 2^(lmax-d) - 1 off the Kraft sum, provided
+        // the sum was at least that much too large.  While it is, and level d has leaves, the
+        // walks repeat unchanged, so a safe number of them (excess >> (lmax - d), never more than
+        // the exact quotient) is taken at once; what is left goes step by step.
+        const uint32_t hd = (uint32_t)__builtin_amdgcn_readlane((int)h, d);
+        const uint32_t walks = (kraft - full) >> (lmax - d);
+        const uint32_t n = hd < walks ? hd : walks;
+        if (n != 0) {
+            if (lane == d) h -= n;
+            if (lane == lmax) h += n;
+            kraft -= n * ((1u << (lmax - d)) - 1u);
+            steps += n * (uint32_t)(lmax - d);
+        } else {
+            if (lane == d) h -= 1;
+            if (lane == d + 1) h += 1;
+            kraft -= 1u << (lmax - d - 1);
+            ++steps;
+        }
     }
     uint32_t holes = full - kraft;
     for (int d = lmax; d >= 2 && holes != 0; --d) {
@@ -637,14 +652,21 @@ __global__ __launch_bounds__(64) void hf_k_chunks_back(const uint32_t nbatch, co
         const uint32_t par4 = reinterpret_cast<const uint32_t*>(S.par + (size_t)c * 256)[lane];
         uint32_t lo = N - 2, hi = N - 2, up = 1;  // the level above: index range and size
         uint32_t h = 0;                           // leaves on level `lane`
+        uint32_t placed = 0;                      // leaves on the levels seen so far
         for (uint32_t d = 1;; ++d) {
+            if (d == (uint32_t)lmax) {  // everything deeper is clamped to lmax anyway
+                if (lane == lmax) h += (uint32_t)N - placed;
+                break;
+            }
             uint32_t cnt = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const uint32_t pk = (par4 >> (8 * i)) & 0xFFu;
                 cnt += (uint32_t)__popcll(__ballot(p[i] < (uint32_t)(N - 2) && pk >= lo && pk <= hi));
             }
-            if ((uint32_t)lane == (d < (uint32_t)lmax ? d : (uint32_t)lmax)) h += 2u * up - cnt;
+            const uint32_t lv = 2u * up - cnt;
+            if ((uint32_t)lane == d) h += lv;
+            placed += lv;
             if (cnt == 0) break;
             hi = lo - 1u;
             lo -= cnt;

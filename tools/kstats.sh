@@ -3,7 +3,7 @@
 # usage: tools/kstats.sh <tag> <python script and args...>
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG -- python3 "$@" > gpurun_out/$TAG.log 2>&1 || { tail -5 gpurun_out/$TAG.log; exit 1; }
+timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG -- python3 "$@" > gpurun_out/$TAG.log 2>&1 || echo "(the probe exited with an error; kernel stats below cover what ran)"
 python3 - "$TAG" <<'PY'
 import csv, glob, sys
 for f in glob.glob("gpurun_out/%s/**/*kernel_stats.csv" % sys.argv[1], recursive=True):
