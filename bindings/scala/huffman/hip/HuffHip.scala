@@ -64,6 +64,11 @@ trait HuffHip extends Library {
   def hf_decode_chunks(ctx: Pointer, dPayload: Pointer, payloadWords: Long, dChunkOff: Pointer,
                        dSide: Pointer, n: Long, layout: Int, dChunkCodebooks: Pointer,
                        dChunkIds: Pointer, nIds: Long, dOut: Pointer, check: Int): Int
+  // decode-on-read into a page pool: chunk dChunkIds(k) -> page dOutSlots(k) of dOut (nSlots pages)
+  def hf_decode_chunks_to(ctx: Pointer, dPayload: Pointer, payloadWords: Long, dChunkOff: Pointer,
+                          dSide: Pointer, n: Long, layout: Int, dChunkCodebooks: Pointer,
+                          dChunkIds: Pointer, dOutSlots: Pointer, nIds: Long, dOut: Pointer,
+                          nSlots: Long, check: Int): Int
   def hf_chunk_codebook_download(ctx: Pointer, dChunkCodebooks: Pointer, chunk: Long,
                                  hCode: Array[Short], hLen: Array[Byte], mode: IntByReference,
                                  entropy: IntByReference): Int

@@ -97,6 +97,8 @@ SIGNATURES = {
                                    _u64p]),
     "hf_decode_chunks": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, C.c_uint64, C.c_int, _vp, _vp,
                                    C.c_uint64, _vp, C.c_int]),
+    "hf_decode_chunks_to": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, C.c_uint64, C.c_int, _vp, _vp,
+                                      _vp, C.c_uint64, _vp, C.c_uint64, C.c_int]),
     "hf_chunk_codebook_download": (C.c_int, [_vp, _vp, C.c_uint64, _u16p, _u8p, _ip, _u32p]),
     "hf_container_plan": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_uint64,
                                     C.POINTER(hf_container_info)]),

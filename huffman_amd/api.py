@@ -583,6 +583,27 @@ class ParrallelHuffmanDecoder(_Module):  # spelling as in decoder/top_decoder.sc
               "hf_decode_chunks")
         return out[:n_out]
 
+    def decode_blocks_to(self, s: EncodedStream, chunk_ids: torch.Tensor, out_slots: torch.Tensor,
+                         page_pool: torch.Tensor, check_stream: bool = True) -> torch.Tensor:
+        """Decode-on-read into a paged buffer: chunk ``chunk_ids[k]`` lands in page
+        ``out_slots[k]`` of ``page_pool`` (a contiguous tensor of whole 16384-element pages)."""
+        assert s.chunk_codebooks is not None
+        for t in (chunk_ids, out_slots):
+            assert t.dtype == torch.int32 and t.is_cuda and t.is_contiguous()
+        assert chunk_ids.numel() == out_slots.numel()
+        assert page_pool.is_cuda and page_pool.is_contiguous() and page_pool.dtype == s.dtype
+        assert page_pool.numel() % HF_CHUNK_SYMS == 0
+        check(L.lib().hf_decode_chunks_to(self.ctx.handle, C.c_void_p(s.payload.data_ptr()),
+                                          s.payload.numel(), C.c_void_p(s.chunk_off.data_ptr()),
+                                          C.c_void_p(_dev_ptr(s.side)), s.n, s.layout,
+                                          C.c_void_p(s.chunk_codebooks.data_ptr()),
+                                          C.c_void_p(chunk_ids.data_ptr()),
+                                          C.c_void_p(out_slots.data_ptr()), chunk_ids.numel(),
+                                          C.c_void_p(page_pool.data_ptr()),
+                                          page_pool.numel() // HF_CHUNK_SYMS,
+                                          1 if check_stream else 0), "hf_decode_chunks_to")
+        return page_pool
+
     def decode(self, s: EncodedStream, out: Optional[torch.Tensor] = None,
                check_stream: bool = True) -> torch.Tensor:
         if s.chunk_codebooks is not None:

@@ -540,28 +540,31 @@ int hf_encode_chunks(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
                          payload_cap_words, d_chunk_off, h_total_words);
 }
 
-int hf_decode_chunks(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
-                     const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n, int layout,
-                     const void* d_chunk_codebooks, const uint32_t* d_chunk_ids, uint64_t n_ids,
-                     void* d_out, int check) {
+static int decode_chunks_common(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
+                                const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n,
+                                int layout, const void* d_chunk_codebooks,
+                                const uint32_t* d_chunk_ids, const uint32_t* d_out_slots,
+                                uint64_t n_slots, uint64_t n_ids, void* d_out, int check) {
     if (!ctx || !layout_ok(layout)) return HF_ERR_ARG;
+    if (d_out_slots && !d_chunk_ids) return HF_ERR_ARG;
     const uint64_t n_work = d_chunk_ids ? n_ids : hf_num_chunks(n);
     if (n_work && (!d_payload || !d_chunk_off || !d_out || !d_chunk_codebooks)) return HF_ERR_ARG;
     if (n_work && payload_words < 4) return HF_ERR_ARG;
     const int lay = norm_layout(layout);
     if (lay == HF_LAYOUT_BF16_EXP && n_work && !d_side) return HF_ERR_ARG;
     if (!aligned16(d_payload) || !aligned16(d_side) || !aligned16(d_out) ||
-        !aligned16(d_chunk_off) || !aligned16(d_chunk_codebooks) || !aligned16(d_chunk_ids))
+        !aligned16(d_chunk_off) || !aligned16(d_chunk_codebooks) || !aligned16(d_chunk_ids) ||
+        !aligned16(d_out_slots))
         return HF_ERR_ALIGN;
-    if (n > (1ull << 40) || n_work > 0x7FFFFFFFull) return HF_ERR_RANGE;
+    if (n > (1ull << 40) || n_work > 0x7FFFFFFFull || n_slots > 0xFFFFFFFFull) return HF_ERR_RANGE;
     if (int rc = use_device(ctx)) return rc;
     HF_HIP(hipMemsetAsync(ctx->d_ctl, 0, 64, ctx->stream));
     if (n_work) {
         tic(ctx);
         hf_launch_decode_chunks(d_payload, payload_words, d_chunk_off, d_side, n, lay,
                                 reinterpret_cast<const hf_chunk_cb*>(d_chunk_codebooks),
-                                d_chunk_ids, n_ids, d_out, ctx->d_ctl + 1, ctx->num_cu,
-                                ctx->stream);
+                                d_chunk_ids, d_out_slots, n_slots, n_ids, d_out, ctx->d_ctl + 1,
+                                ctx->num_cu, ctx->stream);
         toc(ctx);
         HF_HIP(hipGetLastError());
     }
@@ -571,6 +574,25 @@ int hf_decode_chunks(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_wo
         return kerr_to_code(ctx->h_ctl[1]);
     }
     return HF_OK;
+}
+
+int hf_decode_chunks(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
+                     const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n, int layout,
+                     const void* d_chunk_codebooks, const uint32_t* d_chunk_ids, uint64_t n_ids,
+                     void* d_out, int check) {
+    return decode_chunks_common(ctx, d_payload, payload_words, d_chunk_off, d_side, n, layout,
+                                d_chunk_codebooks, d_chunk_ids, nullptr, 0, n_ids, d_out, check);
+}
+
+int hf_decode_chunks_to(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
+                        const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n, int layout,
+                        const void* d_chunk_codebooks, const uint32_t* d_chunk_ids,
+                        const uint32_t* d_out_slots, uint64_t n_ids, void* d_out, uint64_t n_slots,
+                        int check) {
+    if (!d_chunk_ids || !d_out_slots) return HF_ERR_ARG;
+    return decode_chunks_common(ctx, d_payload, payload_words, d_chunk_off, d_side, n, layout,
+                                d_chunk_codebooks, d_chunk_ids, d_out_slots, n_slots, n_ids, d_out,
+                                check);
 }
 
 int hf_chunk_codebook_download(hf_ctx* ctx, const void* d_chunk_codebooks, uint64_t chunk,

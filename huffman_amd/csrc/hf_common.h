@@ -119,8 +119,8 @@ void hf_launch_encode_chunks(const void* d_data, uint64_t n, int layout, const h
 void hf_launch_decode_chunks(const uint32_t* d_payload, uint64_t payload_words,
                              const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n,
                              int layout, const hf_chunk_cb* cbs, const uint32_t* d_chunk_ids,
-                             uint64_t n_ids, void* d_out, uint32_t* d_err, int num_cu,
-                             hipStream_t s);
+                             const uint32_t* d_out_slots, uint64_t n_slots, uint64_t n_ids,
+                             void* d_out, uint32_t* d_err, int num_cu, hipStream_t s);
 void hf_launch_cb_to_wire(const hf_chunk_cb* cbs, uint64_t nchunks, hf_wire_chunk_cb* out,
                           hipStream_t s);
 void hf_launch_wire_to_cb(const hf_wire_chunk_cb* in, uint64_t nchunks, hf_chunk_cb* cbs,

@@ -426,8 +426,8 @@ __global__ __launch_bounds__(kWavesC * 64) void hf_k_decode_chunks(
     const uint32_t* __restrict__ payload, const uint64_t payload_words,
     const uint32_t* __restrict__ chunk_off, const uint8_t* __restrict__ side, const uint64_t n,
     const uint32_t nchunks, const hf_chunk_cb* __restrict__ cbs,
-    const uint32_t* __restrict__ chunk_ids, const uint32_t n_work, void* __restrict__ out,
-    uint32_t* err) {
+    const uint32_t* __restrict__ chunk_ids, const uint32_t* __restrict__ out_slots,
+    const uint32_t n_slots, const uint32_t n_work, void* __restrict__ out, uint32_t* err) {
     __shared__ __attribute__((aligned(16))) uint16_t lut_all[kWavesC][1 << ChunkTables::kBits];
     __shared__ __attribute__((aligned(16))) uint32_t stage[kWavesC][kStageWordsC + kStageSlack];
     __shared__ __attribute__((aligned(16))) uint8_t r2s_all[kWavesC][256];
@@ -438,9 +438,11 @@ __global__ __launch_bounds__(kWavesC * 64) void hf_k_decode_chunks(
     const uint32_t nwaves = gridDim.x * kWavesC;
     const size_t elem_bytes = LAYOUT == HF_LAYOUT_BF16_EXP ? 2 : 1;
     for (uint32_t k = wave; k < n_work; k += nwaves) {
-        // decode-on-read: work item k is chunk chunk_ids[k], written to slot k of `out`
+        // decode-on-read: work item k is chunk chunk_ids[k], written to page k of `out`, or to
+        // page out_slots[k] when the caller names the pages (a paged buffer of n_slots pages)
         const uint32_t c = chunk_ids ? __builtin_amdgcn_readfirstlane(chunk_ids[k]) : k;
-        if (c >= nchunks) {
+        const uint32_t slot = out_slots ? __builtin_amdgcn_readfirstlane(out_slots[k]) : k;
+        if (c >= nchunks || (out_slots && slot >= n_slots)) {
             if (lane == 0) atomicOr(err, HF_KERR_CORRUPT);
             continue;
         }
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(kWavesC * 64) void hf_k_decode_chunks(
         // (the fill descriptors of the build borrow the payload window, staged only afterwards)
         build_chunk_tables(cbs + c, lut_all[wv], r2s_all[wv], stage[wv], tail_all[wv], T, lane);
         const uint8_t* side_chunk = side ? side + first : nullptr;
-        const uint64_t out_first = chunk_ids ? (uint64_t)k * HF_CHUNK_SYMS : first;
+        const uint64_t out_first = chunk_ids ? (uint64_t)slot * HF_CHUNK_SYMS : first;
         void* out_chunk = reinterpret_cast<uint8_t*>(out) + out_first * elem_bytes;
         u64 end;
         if (nvalid == HF_CHUNK_SYMS)
@@ -480,8 +482,8 @@ __global__ __launch_bounds__(kWavesC * 64) void hf_k_decode_chunks(
 void hf_launch_decode_chunks(const uint32_t* d_payload, uint64_t payload_words,
                              const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n,
                              int layout, const hf_chunk_cb* cbs, const uint32_t* d_chunk_ids,
-                             uint64_t n_ids, void* d_out, uint32_t* d_err, int num_cu,
-                             hipStream_t s) {
+                             const uint32_t* d_out_slots, uint64_t n_slots, uint64_t n_ids,
+                             void* d_out, uint32_t* d_err, int num_cu, hipStream_t s) {
     const uint64_t nchunks = (n + HF_CHUNK_SYMS - 1) / HF_CHUNK_SYMS;
     const uint64_t n_work = d_chunk_ids ? n_ids : nchunks;
     if (n_work == 0) return;
@@ -491,12 +493,13 @@ void hf_launch_decode_chunks(const uint32_t* d_payload, uint64_t payload_words,
     if (layout == HF_LAYOUT_BF16_EXP)
         hipLaunchKernelGGL(hf_k_decode_chunks<HF_LAYOUT_BF16_EXP>, dim3((unsigned)grid),
                            dim3(kWavesC * 64), 0, s, d_payload, payload_words, d_chunk_off, d_side,
-                           n, (uint32_t)nchunks, cbs, d_chunk_ids, (uint32_t)n_work, d_out, d_err);
+                           n, (uint32_t)nchunks, cbs, d_chunk_ids, d_out_slots, (uint32_t)n_slots,
+                           (uint32_t)n_work, d_out, d_err);
     else
         hipLaunchKernelGGL(hf_k_decode_chunks<HF_LAYOUT_U8>, dim3((unsigned)grid),
                            dim3(kWavesC * 64), 0, s, d_payload, payload_words, d_chunk_off,
                            (const uint8_t*)nullptr, n, (uint32_t)nchunks, cbs, d_chunk_ids,
-                           (uint32_t)n_work, d_out, d_err);
+                           d_out_slots, (uint32_t)n_slots, (uint32_t)n_work, d_out, d_err);
 }
 
 void hf_launch_decode(const uint32_t* d_payload, uint64_t payload_words,

@@ -219,6 +219,16 @@ int hf_decode_chunks(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_wo
                      const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n, int layout,
                      const void* d_chunk_codebooks, const uint32_t* d_chunk_ids, uint64_t n_ids,
                      void* d_out, int check);
+/* decode-on-read into a paged buffer: listed chunk k (d_chunk_ids[k], a full chunk) goes to page
+ * d_out_slots[k] of d_out, a buffer of n_slots pages of 16384 elements; a slot >= n_slots is
+ * reported as HF_ERR_CORRUPT and never written.  Two items naming the same slot race.  No
+ * counterpart in the reference (its decoder is an empty module, decoder/top_decoder.scala:6-10);
+ * meant for KV-cache pages decoded straight into the page pool of a paged-attention runtime. */
+int hf_decode_chunks_to(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
+                        const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n, int layout,
+                        const void* d_chunk_codebooks, const uint32_t* d_chunk_ids,
+                        const uint32_t* d_out_slots, uint64_t n_ids, void* d_out, uint64_t n_slots,
+                        int check);
 /* bulk read of one record: code/length by symbol, mode, entropy (synchronises) */
 int hf_chunk_codebook_download(hf_ctx* ctx, const void* d_chunk_codebooks, uint64_t chunk,
                                uint16_t* h_code, uint8_t* h_len, int* mode, uint32_t* entropy_q16);

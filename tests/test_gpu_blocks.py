@@ -78,6 +78,43 @@ def test_decode_on_read_random_page_order(hf):
     assert ei.value.code == -7
 
 
+def test_decode_on_read_into_a_page_pool(hf):
+    # listed pages land in caller-named slots of a larger pool; the other slots stay untouched
+    n_pages, pool_pages = 96, 256
+    sym = kv_pages_fp8(n_pages, seed=9)
+    t = torch.from_numpy(sym).to(DEV)
+    s = hf.EntropyAwareHuffmanSystem().encode_blocks(t, mode=hf.HF_MODE_HUFFMAN)
+    rng = np.random.default_rng(1)
+    ids = torch.from_numpy(rng.permutation(n_pages)[:50].astype(np.int32)).to(DEV)
+    slots = torch.from_numpy(rng.permutation(pool_pages)[:50].astype(np.int32)).to(DEV)
+    pool = torch.full((pool_pages * CH,), 0xEE, dtype=torch.uint8, device=DEV)
+    dec = hf.ParrallelHuffmanDecoder()
+    dec.decode_blocks_to(s, ids, slots, pool)
+    exp = torch.full((pool_pages, CH), 0xEE, dtype=torch.uint8, device=DEV)
+    exp[slots.long()] = t.view(n_pages, CH)[ids.long()]
+    assert torch.equal(pool.view(pool_pages, CH), exp)
+    # a slot past the pool is reported and nothing is written for it
+    bad_slots = slots.clone()
+    bad_slots[3] = pool_pages
+    pool2 = torch.full((pool_pages * CH,), 0xEE, dtype=torch.uint8, device=DEV)
+    with pytest.raises(hf.HuffhipError) as ei:
+        dec.decode_blocks_to(s, ids, bad_slots, pool2)
+    assert ei.value.code == -7
+    exp[slots[3].long()] = 0xEE
+    assert torch.equal(pool2.view(pool_pages, CH), exp)
+    # bf16 pages go the same way
+    w = gaussian_bf16(6 * CH, seed=21)
+    tb = torch.from_numpy(w.view(np.int16)).to(DEV).view(torch.bfloat16)
+    sb = hf.EntropyAwareHuffmanSystem().encode_blocks(tb, mode=hf.HF_MODE_HUFFMAN)
+    idb = torch.tensor([5, 0, 3], dtype=torch.int32, device=DEV)
+    slb = torch.tensor([1, 7, 2], dtype=torch.int32, device=DEV)
+    poolb = torch.zeros(8 * CH, dtype=torch.bfloat16, device=DEV)
+    dec.decode_blocks_to(sb, idb, slb, poolb)
+    expb = torch.zeros(8, CH, dtype=torch.int16, device=DEV)
+    expb[slb.long()] = tb.view(torch.int16).view(6, CH)[idb.long()]
+    assert torch.equal(poolb.view(torch.int16).view(8, CH), expb)
+
+
 @pytest.mark.parametrize("kind", ["one", "two", "fib", "geometric", "uniform"])
 def test_degenerate_blocks(hf, orc, kind):
     # 1-2 symbol blocks, blocks that need the length limiter, ragged tail
