@@ -374,6 +374,15 @@ class EncodedStream:
         return raw / max(1, self.compressed_bytes())
 
     # -- container (wire format v1, include/huffhip.h) ---------------------------------------------
+    def container_bytes(self) -> int:
+        """Size of this stream's container (host arithmetic, nothing is packed)."""
+        assert self.total_words is not None, "encode with sync=True first"
+        info = L.hf_container_info()
+        check(L.lib().hf_container_plan(self.n, self.layout,
+                                        1 if self.chunk_codebooks is not None else 0,
+                                        self.total_words, C.byref(info)), "hf_container_plan")
+        return int(info.total_bytes)
+
     def to_container(self, ctx: Optional["Context"] = None) -> torch.Tensor:
         """One self-describing uint8 device tensor: header, codebook(s), chunk offsets, side
         bytes, payload."""

@@ -39,6 +39,22 @@ def allreduce_histogram(freq256: torch.Tensor, group=None) -> torch.Tensor:
     return freq256
 
 
+def shard_directory(lo: int, hi: int, payload_words: int, stored_bytes: int,
+                    device: Optional[torch.device] = None, group=None) -> torch.Tensor:
+    """The shard directory of a partitioned tensor: int64[world][4], row r = (first element, end
+    element, payload words, stored bytes) of rank r's stream.  The streams are independent, so
+    this is all a reader needs to find and decode any shard; it costs one all-gather of 32 bytes
+    per rank (RCCL with the nccl backend, which wants `device` to be this rank's GPU)."""
+    mine = torch.tensor([lo, hi, payload_words, stored_bytes], dtype=torch.int64,
+                        device=device if device is not None else "cpu")
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return mine.view(1, 4)
+    world = dist.get_world_size(group)
+    out = torch.empty(world * 4, dtype=torch.int64, device=mine.device)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    return out.view(world, 4)
+
+
 class ShardedCodec:
     """Encode / decode this rank's shard of a tensor that is partitioned over the ranks."""
 
@@ -61,3 +77,9 @@ class ShardedCodec:
 
     def decode(self, stream, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         return self.decoder.decode(stream, out=out)
+
+    def directory(self, stream, lo: int) -> torch.Tensor:
+        """Shard directory (see `shard_directory`) for this rank's `stream` starting at element
+        `lo` of the whole tensor; stored bytes are those of the stream's container."""
+        return shard_directory(lo, lo + stream.n, stream.total_words, stream.container_bytes(),
+                               device=stream.payload.device, group=self.group)

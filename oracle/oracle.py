@@ -278,6 +278,14 @@ def num_chunks(n: int) -> int:
     return (n + CHUNK_SYMS - 1) // CHUNK_SYMS
 
 
+def container_bytes(n, layout, kind, payload_words) -> int:
+    """Size of a version-1 container (kind 0: one codebook, 1: one per chunk)."""
+    l = lib()
+    l.orc_container_bytes.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_uint64]
+    l.orc_container_bytes.restype = C.c_uint64
+    return int(l.orc_container_bytes(n, layout, kind, payload_words))
+
+
 def container_pack(n, layout, payload, chunk_off, side=None, code=None, lens=None, mode=1,
                    entropy_q16=0, rank2sym=None, len_by_rank=None, modes=None, entropies=None):
     """The container (wire format v1) as bytes.  One codebook (code, lens, mode, entropy_q16) or

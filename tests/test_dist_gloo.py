@@ -50,7 +50,7 @@ def _worker(rank, world, port, n, seed, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from huffman_amd.dist import allreduce_histogram, shard_range
+        from huffman_amd.dist import allreduce_histogram, shard_directory, shard_range
         from oracle import oracle as orc
         from conftest import gaussian_bf16
         w = gaussian_bf16(n, seed)                       # every rank builds the same tensor
@@ -64,8 +64,10 @@ def _worker(rank, world, port, n, seed, q):
         # shard streams are independent: encode this rank's range with the global table
         payload, off = orc.rp_encode(sym[lo:hi], code, lens)
         back = orc.rp_decode(payload, off, hi - lo, code, lens)
+        stored = orc.container_bytes(hi - lo, orc.LAYOUT_BF16_EXP, 0, int(payload.size))
+        directory = shard_directory(lo, hi, int(payload.size), stored)
         q.put((rank, lo, hi, glob.tolist(), code.tolist(), lens.tolist(), int(payload.size),
-               bool(np.array_equal(back, sym[lo:hi]))))
+               bool(np.array_equal(back, sym[lo:hi])), directory.tolist()))
     finally:
         dist.destroy_process_group()
 
@@ -91,5 +93,9 @@ def test_global_codebook_two_ranks_gloo(orc):
         assert r[3] == whole.tolist()                  # all-reduced histogram = global histogram
         assert r[7]                                     # the shard round-trips
     assert res[0][4] == res[1][4] and res[0][5] == res[1][5]  # identical codebooks, no broadcast
+    # every rank holds the same shard directory: ranges, payload words, stored bytes per shard
+    assert res[0][8] == res[1][8] and len(res[0][8]) == world
+    for r in res:
+        assert res[0][8][r[0]][:3] == [r[1], r[2], r[6]] and res[0][8][r[0]][3] > 4 * r[6]
     code, lens = orc.rp_system_codebook(whole, 64, 0, 16)
     assert res[0][4] == code.tolist() and res[0][5] == lens.tolist()

@@ -141,3 +141,16 @@ def test_bad_containers_are_rejected(hf, orc):
     rc = L.lib().hf_container_codebook(ctx.handle, C.c_void_p(bad.data_ptr()), C.byref(info),
                                        C.c_void_p(cbs.data_ptr()))
     assert rc == L.HF_ERR_CORRUPT
+
+
+def test_sharded_codec_single_rank_and_its_directory(hf):
+    # the multi-rank helper on one rank (no process group): same stream, a one-row directory whose
+    # stored size is the size of the container actually packed
+    from huffman_amd.dist import ShardedCodec
+    w = torch.from_numpy(gaussian_bf16(3 * 16384 + 999, seed=31).view(np.int16)).to(DEV).view(torch.bfloat16)
+    codec = ShardedCodec(global_codebook=True)
+    s = codec.encode(w, mode=hf.HF_MODE_HUFFMAN)
+    d = codec.directory(s, lo=0)
+    assert tuple(d.shape) == (1, 4)
+    assert d[0].tolist() == [0, w.numel(), s.total_words, s.to_container().numel()]
+    assert torch.equal(codec.decode(s).view(torch.int16), w.view(torch.int16))
