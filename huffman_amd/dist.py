@@ -29,6 +29,31 @@ def shard_range(n: int, rank: int, world: int, align: int = HF_CHUNK_SYMS) -> Tu
     return min(n, c_lo * align), min(n, c_hi * align)
 
 
+def assign_tensors(sizes, world: int, split_above: Optional[int] = None):
+    """Place the tensors of a collection on `world` ranks: a tensor goes whole to one rank, the
+    largest first to the rank with the least bytes so far (ties to the lower rank), except that
+    a tensor of more than `split_above` elements is partitioned over all ranks with
+    `shard_range`.  Returns one entry per tensor: the rank, or -1 for "sharded over all ranks".
+    Deterministic, so every rank computes the same placement without talking."""
+    if world < 1:
+        raise ValueError("bad world size")
+    load = [0] * world
+    place = [0] * len(sizes)
+    order = sorted(range(len(sizes)), key=lambda i: (-int(sizes[i]), i))
+    for i in order:
+        n = int(sizes[i])
+        if split_above is not None and n > split_above:
+            place[i] = -1
+            for r in range(world):
+                lo, hi = shard_range(n, r, world)
+                load[r] += hi - lo
+            continue
+        r = min(range(world), key=lambda k: (load[k], k))
+        place[i] = r
+        load[r] += n
+    return place
+
+
 def allreduce_histogram(freq256: torch.Tensor, group=None) -> torch.Tensor:
     """Sum the per-rank symbol counts in place (int64[256]).  With the nccl backend this is the
     RCCL all-reduce over xGMI; with gloo (CPU tests) the same call on host tensors."""

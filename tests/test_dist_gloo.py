@@ -35,6 +35,22 @@ def test_shard_range_properties():
         shard_range(10, 2, 2)
 
 
+def test_assign_tensors_is_balanced_and_deterministic():
+    from huffman_amd.dist import assign_tensors
+    rng = np.random.default_rng(3)
+    sizes = [int(x) for x in rng.integers(1, 1 << 20, 200)] + [1 << 26]
+    for world in (1, 2, 8):
+        place = assign_tensors(sizes, world, split_above=1 << 24)
+        assert place == assign_tensors(list(sizes), world, split_above=1 << 24)
+        assert place[-1] == (-1 if world >= 1 else 0)          # the oversized one is sharded
+        assert all(0 <= p < world for p in place[:-1])
+        load = [sum(s for s, p in zip(sizes, place) if p == r) for r in range(world)]
+        assert max(load) - min(load) <= max(sizes[:-1])        # greedy bound: one tensor apart
+    assert assign_tensors([5, 5, 5], 2) == [0, 1, 0]           # ties go to the lower rank
+    with pytest.raises(ValueError):
+        assign_tensors([1], 0)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
