@@ -19,3 +19,15 @@ def test_oracle_selftest_under_sanitizers():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "oracle selftest ok" in r.stdout
+
+
+def test_host_side_of_the_c_abi_under_sanitizers():
+    # hf_api.hip's host code (argument checks, host arithmetic, context handling) compiled with
+    # -Xarch_host -fsanitize=address,undefined and driven by huffman_amd/csrc/abi_selftest.c;
+    # device code is untouched and no GPU is needed
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "huffman_amd", "csrc"), "sanitize-host"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "abi selftest ok" in r.stdout
