@@ -475,3 +475,27 @@ def test_config2_full_size_properties(hf):
     out = hf.ParrallelHuffmanDecoder().decode(s)
     assert torch.equal(out.view(torch.int16), w.view(torch.int16))
     assert 1.45 < s.ratio() < 1.52
+
+
+def test_seeded_random_streams_against_the_oracle(hf, orc):
+    # 60 streams of random length, symbol distribution (Dirichlet with random concentration, so
+    # from near-uniform to a few hot symbols), layout and mode: histogram, codebook, payload,
+    # offsets, side bytes and round trip against the oracle, bit for bit
+    rng = np.random.default_rng(20240611)
+    for case in range(60):
+        n = int(rng.choice([rng.integers(1, 600), rng.integers(600, 70000), rng.integers(70000, 400000)]))
+        alpha = float(10.0 ** rng.uniform(-2.5, 1.0))
+        k = int(rng.integers(1, 257))
+        p = rng.dirichlet(np.full(k, alpha))
+        syms = rng.permutation(256)[:k]
+        sym = syms[rng.choice(k, size=n, p=p)].astype(np.uint8)
+        mode = int(rng.choice([hf.HF_MODE_HUFFMAN, hf.HF_MODE_HUFFMAN, hf.HF_MODE_AUTO, hf.HF_MODE_BYPASS]))
+        if rng.random() < 0.5:
+            system_roundtrip(hf, orc, dev_u8(sym), sym, mode=mode)
+        else:
+            low = rng.integers(0, 128, n).astype(np.uint16)
+            sign = rng.integers(0, 2, n).astype(np.uint16)
+            w = (sign << 15) | (sym.astype(np.uint16) << 7) | low
+            s2, side = orc.symbolize(w, orc.LAYOUT_BF16_EXP)
+            assert np.array_equal(s2, sym)
+            system_roundtrip(hf, orc, dev_bf16(w), sym, mode=mode, side=side)
