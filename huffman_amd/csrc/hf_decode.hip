@@ -398,19 +398,33 @@ __device__ void build_chunk_tables(const hf_chunk_cb* __restrict__ ccb, uint16_t
         const uint32_t span = 1u << (B - L);
         for (uint32_t k = lane; k < span; k += 64) lut[first + k] = val;
     }
-    // narrow codes (at most 32 entries each): every lane fills its own ranks
+    // narrow codes (at most 32 entries each): every lane fills its own ranks.  A code's span
+    // starts at a multiple of its size (canonical codes, lengths never decreasing), so the span
+    // is written with the widest aligned store that fits: 16 bytes for 8 entries and more.
+    auto fill = [](uint16_t* base, const uint32_t first, const uint32_t span, const uint16_t val) {
+        const uint32_t v2 = (uint32_t)val | ((uint32_t)val << 16);
+        if (span >= 8) {
+            for (uint32_t k = 0; k < span; k += 8)
+                *reinterpret_cast<uint4*>(base + first + k) = make_uint4(v2, v2, v2, v2);
+        } else if (span == 4) {
+            *reinterpret_cast<uint2*>(base + first) = make_uint2(v2, v2);
+        } else if (span == 2) {
+            *reinterpret_cast<uint32_t*>(base + first) = v2;
+        } else {
+            base[first] = val;
+        }
+    };
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint16_t val = (uint16_t)((((syms4 >> (8 * i)) & 0xFFu) << 8) | len[i]);
         if (len[i] >= B - 5 && len[i] <= B) {
             const uint32_t first = ((lane_base + start[i]) >> (16 - B)) & ((1u << B) - 1u);
-            const uint32_t span = 1u << (B - len[i]);
-            for (uint32_t k = 0; k < span; ++k) lut[first + k] = val;
+            fill(lut, first, 1u << (B - len[i]), val);
         }
         if (T.tail_n != 0 && len[i] > B && len[i] <= 16) {
-            const uint32_t first = lane_base + start[i] - T.start[0];
-            const uint32_t span = 1u << (16 - len[i]);
-            for (uint32_t k = 0; k < span; ++k) tail[first + k] = val;
+            // (the long codes' part of the code space starts at a multiple of 2^(16-B), so a
+            // span keeps its alignment relative to the table)
+            fill(tail, lane_base + start[i] - T.start[0], 1u << (16 - len[i]), val);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
