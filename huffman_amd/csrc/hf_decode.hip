@@ -353,17 +353,24 @@ __device__ void build_chunk_tables(const hf_chunk_cb* __restrict__ ccb, uint16_t
         if (lane >= o) incl += v;
     }
     const uint32_t lane_base = incl - lane_total;
-    // counts per length -> blocks of the long codes
-    uint32_t cnt_below = 0, start_acc = 0;
-    for (uint32_t d = 1; d <= 16; ++d) {
+    // blocks of the long codes: where each long length starts in the code space and the rank of
+    // its first code.  Everything before them is the short codes taken together.
+    uint32_t cnt_below = 0, short_width = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool is_short = len[i] >= 1 && len[i] <= (uint32_t)B;
+        cnt_below += (uint32_t)__popcll(__ballot(is_short));
+        short_width += is_short ? width[i] : 0u;
+    }
+    uint32_t start_acc = hf_wave_sum_u32(short_width);
+#pragma unroll
+    for (uint32_t d = B + 1; d <= 16; ++d) {
         uint32_t c = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) c += (uint32_t)__popcll(__ballot(len[i] == d));
-        if (d > (uint32_t)B) {
-            T.start[d - B - 1] = start_acc;
-            T.off[d - B - 1] = cnt_below;
-            T.end[d - B - 1] = start_acc + (c << (16 - d));
-        }
+        T.start[d - B - 1] = start_acc;
+        T.off[d - B - 1] = cnt_below;
+        T.end[d - B - 1] = start_acc + (c << (16 - d));
         cnt_below += c;
         start_acc += c << (16 - d);
     }
