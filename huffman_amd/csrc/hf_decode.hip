@@ -21,7 +21,7 @@ namespace {
 typedef unsigned long long u64;
 constexpr int kWaves = 8;
 constexpr int kStageWords = 1024;   // payload window per wavefront, stream-wide tables (4 KiB)
-constexpr int kStageWordsC = 1024;  // payload window per wavefront, per-chunk tables (4 KiB)
+constexpr int kStageWordsC = 512;   // payload window per wavefront, per-chunk tables (2 KiB)
 constexpr int kStageSlack = 64;    // never staged: room for the reads of a clamped position
 
 // Tables of a stream-wide codebook (any prefix-free code): shared by the workgroup.
@@ -508,7 +508,7 @@ void hf_launch_decode_chunks(const uint32_t* d_payload, uint64_t payload_words,
     const uint64_t nchunks = (n + HF_CHUNK_SYMS - 1) / HF_CHUNK_SYMS;
     const uint64_t n_work = d_chunk_ids ? n_ids : nchunks;
     if (n_work == 0) return;
-    // one chunk per wavefront (four 38 KiB workgroups fit one CU's LDS)
+    // one chunk per wavefront (five 30 KiB workgroups fit one CU's LDS)
     (void)num_cu;
     const uint64_t grid = (n_work + kWavesC - 1) / kWavesC;
     if (layout == HF_LAYOUT_BF16_EXP)
