@@ -499,3 +499,44 @@ def test_seeded_random_streams_against_the_oracle(hf, orc):
             s2, side = orc.symbolize(w, orc.LAYOUT_BF16_EXP)
             assert np.array_equal(s2, sym)
             system_roundtrip(hf, orc, dev_bf16(w), sym, mode=mode, side=side)
+
+
+def test_two_contexts_on_two_streams_overlap(hf, orc):
+    # one context per stream, both streams busy at once with no host synchronisation in between:
+    # every context has its own descriptors, ticket, spill area and error word, so the streams
+    # must come out as if encoded alone
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    a = dev_bf16(gaussian_bf16(40 * 16384 + 77, seed=41))
+    b = dev_u8(skewed_symbols(25 * 16384 + 5, 42, "geometric"))
+    torch.cuda.synchronize()
+    out = {}
+    with torch.cuda.stream(s1):
+        c1 = hf.Context(stream=s1)
+        sys1 = hf.EntropyAwareHuffmanSystem(ctx=c1)
+    with torch.cuda.stream(s2):
+        c2 = hf.Context(stream=s2)
+        sys2 = hf.EntropyAwareHuffmanSystem(ctx=c2)
+    for rep in range(3):  # interleaved launches, nothing waits for anything
+        with torch.cuda.stream(s1):
+            f1 = sys1.histogram(a)
+            cb1 = sys1.codebook(f1, hf.HF_MODE_HUFFMAN)
+            out["a"] = sys1.encode_with(a, cb1, sync=False)
+        with torch.cuda.stream(s2):
+            f2 = sys2.histogram(b)
+            cb2 = sys2.codebook(f2, hf.HF_MODE_HUFFMAN)
+            out["b"] = sys2.encode_with(b, cb2, sync=False)
+    c1.sync()
+    c2.sync()
+    torch.cuda.synchronize()
+    for key, data, ctx in (("a", a, c1), ("b", b, c2)):
+        st = out[key]
+        nch = (data.numel() + 16383) // 16384
+        st.total_words = int(st.chunk_off[nch].item()) & 0xFFFFFFFF
+        alone = hf.EntropyAwareHuffmanSystem().encode(data, mode=hf.HF_MODE_HUFFMAN)
+        assert st.total_words == alone.total_words
+        assert torch.equal(st.payload[: st.total_words], alone.payload[: alone.total_words])
+        assert torch.equal(st.chunk_off[: nch + 1], alone.chunk_off[: nch + 1])
+        back = hf.ParrallelHuffmanDecoder(ctx=ctx).decode(st)
+        ctx.sync()
+        assert torch.equal(back.view(torch.uint8), data.view(torch.uint8))
