@@ -379,6 +379,72 @@ __global__ __launch_bounds__(64) void hf_k_stage(hf_stage_io* io, const int N, c
     if (lane == 0) io->status = 0;
 }
 
+// HuffmanTreeBuilder for the system kernel (N = 256): the same two-queue merge as stage_tree, but
+// only what the next stage needs is kept.  That stage works on the number of leaves per level,
+// which follows from the parent links of the internal nodes alone (they leave the FIFO in creation
+// order, so a tree level is a contiguous range of them; see hf_k_chunks_back).  Weights are all
+// that matters for it: the leaf queue is the filtered counts in rank order read backwards (no
+// second sort), and no child link, leaf parent or leaf depth is written.  Returns the leaves per
+// level, level d in lane d, depths above lmax counted at lmax.
+__device__ __forceinline__ uint32_t system_tree_levels(CbLds& L, const u64* sorted, const u64 thr,
+                                                       const int lmax, const int lane) {
+    constexpr int N = 256;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = lane + 64 * i;
+        const u64 f = sorted[N - 1 - q];
+        L.lq_w[q] = f < thr ? 0ull : f;  // sFilter, entropy_aware_tree_builder.scala:61-66
+    }
+    __syncthreads();
+    if (lane == 0) {
+        int li = 0, ii = N;
+        u64 lw = L.lq_w[0], iw = 0;
+        for (int k = N; k < 2 * N - 1; ++k) {
+            u64 wt[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const bool leaf = (li < N) && (ii >= k || lw <= iw);
+                if (leaf) {
+                    wt[p] = lw;
+                    ++li;
+                    lw = li < N ? L.lq_w[li] : 0;
+                } else {
+                    L.parent[ii] = (uint16_t)k;
+                    wt[p] = iw;
+                    ++ii;
+                    iw = ii < k ? L.w[ii] : 0;
+                }
+            }
+            const u64 ws = wt[0] + wt[1];
+            L.w[k] = ws;
+            if (ii == k) iw = ws;
+        }
+    }
+    __syncthreads();
+    uint32_t par[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) par[i] = lane + 64 * i < N - 2 ? L.parent[N + lane + 64 * i] : 0u;
+    uint32_t lo = 2 * N - 2, hi = 2 * N - 2, up = 1, h = 0, placed = 0;  // the root alone
+    for (uint32_t d = 1;; ++d) {
+        if (d == (uint32_t)lmax) {
+            if (lane == lmax) h += (uint32_t)N - placed;
+            break;
+        }
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            cnt += (uint32_t)__popcll(__ballot(lane + 64 * i < N - 2 && par[i] >= lo && par[i] <= hi));
+        const uint32_t lv = 2u * up - cnt;
+        if ((uint32_t)lane == d) h += lv;
+        placed += lv;
+        if (cnt == 0) break;
+        hi = lo - 1u;
+        lo -= cnt;
+        up = cnt;
+    }
+    return h;
+}
+
 // ---- front half of EntropyAwareHuffmanSystem, device to device --------------------------------
 // stat counts (by raw symbol) -> sort -> entropy decision -> filter -> tree -> adjust(16) ->
 // canonical codes over ranks -> scatter through rank2sym (the RTL indexes the rank-ordered
@@ -400,13 +466,20 @@ __global__ __launch_bounds__(64) void hf_k_system(const u64* __restrict__ freq25
     __syncthreads();
     u64 bits = 0, cnt = 0;
     if (mode == HF_MODE_HUFFMAN) {
-        for (int e = lane; e < N; e += 64) {
-            const u64 f = sorted[e];
-            L.w[e] = f < thr ? 0ull : f;
+        uint32_t h = system_tree_levels(L, sorted, thr, HF_MAX_CODE_LEN, lane);
+        adjust_levels(h, HF_MAX_CODE_LEN, lane);
+        {
+            const uint32_t pidx[4] = {(uint32_t)lane, (uint32_t)lane + 64u, (uint32_t)lane + 128u,
+                                      (uint32_t)lane + 192u};
+            uint32_t dep[4], code[4];
+            assign_codes(h, HF_MAX_CODE_LEN, lane, pidx, dep, code);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                L.adj[pidx[i]] = (uint16_t)dep[i];
+                L.code[pidx[i]] = (uint16_t)code[i];
+            }
         }
         __syncthreads();
-        stage_tree(L, N, lane);
-        stage_adjust(L, N, HF_MAX_CODE_LEN, lane);
         for (int p = lane; p < N; p += 64) {
             const u64 f = sorted[p];
             bits += f * (u64)L.adj[p];
