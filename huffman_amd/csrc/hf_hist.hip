@@ -88,26 +88,37 @@ __global__ __launch_bounds__(kThreads) void hf_k_hist(const uint4* __restrict__ 
     if (sum) atomicAdd(&freq[tid], (unsigned long long)sum);
 }
 
-// One histogram per 16384-symbol chunk (a KV-cache page): one wavefront per chunk, 8 copies of
-// the 256 counters in LDS (lane l adds into copy l mod 8), folded and written as uint32[256].
-constexpr int kChunkCopies = 8;
+// One histogram per 16384-symbol chunk (a KV-cache page): one wavefront per chunk.  A chunk holds
+// at most 16384 of any symbol, so a counter fits 16 bits and two bins share a 32-bit LDS word
+// (bins 2k and 2k+1 in the halves of word k); that halves the table and pays for 16 copies of it
+// in the 8 KiB that 8 copies of 32-bit counters took, lane l adding into copy l mod 16.  Measured
+// on 65536 fp8 pages: 16 packed copies 0.198 ms, 8 unpacked 0.24, 8 packed 0.246, 32 packed (a
+// bank per lane, but 16 KiB per wavefront and 8 wavefronts per CU instead of 20) 0.261.
+// Folded and written as uint32[256].
+constexpr int kChunkCopies = 16;
 constexpr int kChunkWaves = 4;
+constexpr int kChunkWords = 128 * kChunkCopies;  // 8 KiB per wavefront
 
 template <int LAYOUT>
 __global__ __launch_bounds__(kChunkWaves * 64) void hf_k_hist_chunks(
     const void* __restrict__ data, const uint64_t n, const uint32_t nchunks,
     uint32_t* __restrict__ freq_chunks) {
-    __shared__ uint32_t h_all[kChunkWaves][256 * kChunkCopies];
+    __shared__ __attribute__((aligned(16))) uint32_t h_all[kChunkWaves][kChunkWords];
     const int lane = hf_lane();
     const int wv = threadIdx.x >> 6;
     uint32_t* h = h_all[wv];
     const uint32_t c = blockIdx.x * kChunkWaves + wv;
     if (c >= nchunks) return;
-    for (int i = lane; i < 256 * kChunkCopies; i += 64) h[i] = 0;
+#pragma unroll
+    for (int k = 0; k < kChunkWords / 4 / 64; ++k)
+        reinterpret_cast<uint4*>(h)[k * 64 + lane] = make_uint4(0, 0, 0, 0);
     const uint64_t first = (uint64_t)c * HF_CHUNK_SYMS;
     const uint64_t left = n - first;
     const uint32_t nvalid = left < HF_CHUNK_SYMS ? (uint32_t)left : HF_CHUNK_SYMS;
     const uint32_t copy = lane & (kChunkCopies - 1);
+    auto count = [&](const uint32_t sym) {
+        atomicAdd(&h[(sym >> 1) * kChunkCopies + copy], 1u << ((sym & 1u) * 16u));
+    };
     const uint4* const pv = reinterpret_cast<const uint4*>(
         reinterpret_cast<const uint8_t*>(data) + first * (LAYOUT == HF_LAYOUT_BF16_EXP ? 2 : 1));
     constexpr uint32_t kPerVec = LAYOUT == HF_LAYOUT_BF16_EXP ? 8 : 16;
@@ -116,16 +127,20 @@ __global__ __launch_bounds__(kChunkWaves * 64) void hf_k_hist_chunks(
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (LAYOUT == HF_LAYOUT_BF16_EXP) {
-                atomicAdd(&h[((w[i] >> 7) & 0xFFu) * kChunkCopies + copy], 1u);
-                atomicAdd(&h[((w[i] >> 23) & 0xFFu) * kChunkCopies + copy], 1u);
+                count((w[i] >> 7) & 0xFFu);
+                count((w[i] >> 23) & 0xFFu);
             } else {
-                atomicAdd(&h[(w[i] & 0xFFu) * kChunkCopies + copy], 1u);
-                atomicAdd(&h[((w[i] >> 8) & 0xFFu) * kChunkCopies + copy], 1u);
-                atomicAdd(&h[((w[i] >> 16) & 0xFFu) * kChunkCopies + copy], 1u);
-                atomicAdd(&h[(w[i] >> 24) * kChunkCopies + copy], 1u);
+                count(w[i] & 0xFFu);
+                count((w[i] >> 8) & 0xFFu);
+                count((w[i] >> 16) & 0xFFu);
+                count(w[i] >> 24);
             }
         }
     };
+    // the wavefront's own LDS operations complete in order; no other wavefront touches h
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (nvalid == HF_CHUNK_SYMS) {
         // a whole page: its loads are issued 16 at a time before any of them is consumed
         constexpr int kBatch = 16;
@@ -142,25 +157,27 @@ __global__ __launch_bounds__(kChunkWaves * 64) void hf_k_hist_chunks(
         const uint32_t nvec = nvalid / kPerVec;
         for (uint32_t v = lane; v < nvec; v += 64) count_vec(pv[v]);
         for (uint32_t i = nvec * kPerVec + lane; i < nvalid; i += 64) {
-            if (LAYOUT == HF_LAYOUT_BF16_EXP) {
-                const uint16_t e = reinterpret_cast<const uint16_t*>(pv)[i];
-                atomicAdd(&h[((e >> 7) & 0xFFu) * kChunkCopies + copy], 1u);
-            } else {
-                atomicAdd(&h[reinterpret_cast<const uint8_t*>(pv)[i] * kChunkCopies + copy], 1u);
-            }
+            if (LAYOUT == HF_LAYOUT_BF16_EXP)
+                count((reinterpret_cast<const uint16_t*>(pv)[i] >> 7) & 0xFFu);
+            else
+                count(reinterpret_cast<const uint8_t*>(pv)[i]);
         }
     }
-    // the wavefront's own LDS operations complete in order; no other wavefront touches h
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // lane l folds the bin pairs l and l + 64 (bins 2l, 2l+1 and 128+2l, 129+2l); the rotation
+    // keeps the reads of a 32-lane group on 32 different banks.  No half can carry into the
+    // other: a chunk holds at most 16384 symbols.
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int s = lane + 64 * k;
+    for (int k = 0; k < 2; ++k) {
+        const int pair = lane + 64 * k;
         uint32_t sum = 0;
 #pragma unroll
-        for (int i = 0; i < kChunkCopies; ++i) sum += h[s * kChunkCopies + ((i + lane) & (kChunkCopies - 1))];
-        freq_chunks[(size_t)c * 256 + s] = sum;
+        for (int i = 0; i < kChunkCopies; ++i)
+            sum += h[pair * kChunkCopies + ((i + lane) & (kChunkCopies - 1))];
+        reinterpret_cast<uint2*>(freq_chunks + (size_t)c * 256)[pair] =
+            make_uint2(sum & 0xFFFFu, sum >> 16);
     }
 }
 
