@@ -1,6 +1,8 @@
 """GPU parity of the per-block path: one codebook per 16384-symbol chunk (fp8 KV-cache pages
 with per-block EntropyAwareTreeBuilder codebooks, decode-on-read), checked against the CPU
 oracle run block by block."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -285,31 +287,33 @@ def test_config3_full_size(hf, orc):
 def test_seeded_random_pages_against_the_oracle(hf, orc):
     # 48 pages, each with its own random alphabet size and skew (from one symbol to all 256,
     # near-uniform to a few hot symbols), a ragged last page, all four modes
-    rng = np.random.default_rng(77)
+    # (HF_SOAK_SEED / HF_SOAK_SCALE: another seed, and that many times the pages, for a soak run)
+    rng = np.random.default_rng(int(os.environ.get("HF_SOAK_SEED", "77")))
+    P = 48 * int(os.environ.get("HF_SOAK_SCALE", "1"))
     pages = []
-    for _ in range(48):
+    for _ in range(P):
         k = int(rng.choice([1, 2, 3, rng.integers(4, 40), rng.integers(40, 257)]))
         alpha = float(10.0 ** rng.uniform(-2.5, 1.0))
         p = rng.dirichlet(np.full(k, alpha))
         syms = rng.permutation(256)[:k]
         pages.append(syms[rng.choice(k, size=CH, p=p)].astype(np.uint8))
-    sym = np.concatenate(pages)[: 47 * CH + 5000]
+    sym = np.concatenate(pages)[: (P - 1) * CH + 5000]
     t = torch.from_numpy(sym).to(DEV)
     sys_ = hf.EntropyAwareHuffmanSystem()
     for mode in (hf.HF_MODE_HUFFMAN, hf.HF_MODE_AUTO, hf.HF_MODE_BYPASS):
         s = sys_.encode_blocks(t, mode=mode)
         payload, off, books = oracle_blocks(orc, sym, mode)
         assert s.total_words == payload.size
-        assert np.array_equal(s.chunk_off[: 49].cpu().numpy().view(np.uint32), off)
+        assert np.array_equal(s.chunk_off[: P + 1].cpu().numpy().view(np.uint32), off)
         assert np.array_equal(s.payload[: payload.size].cpu().numpy().view(np.uint32), payload)
-        for c in range(48):
+        for c in range(P):
             code, lens, m, ent = sys_.block_codebook(s, c)
             assert (m, ent) == (books[c][2], books[c][3])
             assert np.array_equal(code, books[c][0]) and np.array_equal(lens, books[c][1]), c
         assert torch.equal(hf.ParrallelHuffmanDecoder().decode(s), t)
     # HF_MODE_BEST: per page, Huffman only where it pays; the stream still round-trips
     s = sys_.encode_blocks(t, mode=hf.HF_MODE_BEST)
-    for c in range(48):
+    for c in range(P):
         blk = sym[c * CH:(c + 1) * CH]
         f = orc.aw_symbol_stat(blk, 256, 32)
         _, lens_h = orc.rp_system_codebook(f, 64, 0, 16)

@@ -2,6 +2,8 @@
 
 Known-answer vectors taken from the reference's own specs are marked with their source lines.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -481,8 +483,9 @@ def test_seeded_random_streams_against_the_oracle(hf, orc):
     # 60 streams of random length, symbol distribution (Dirichlet with random concentration, so
     # from near-uniform to a few hot symbols), layout and mode: histogram, codebook, payload,
     # offsets, side bytes and round trip against the oracle, bit for bit
-    rng = np.random.default_rng(20240611)
-    for case in range(60):
+    # (HF_SOAK_SEED / HF_SOAK_SCALE: another seed, and that many times the cases, for a soak run)
+    rng = np.random.default_rng(int(os.environ.get("HF_SOAK_SEED", "20240611")))
+    for case in range(60 * int(os.environ.get("HF_SOAK_SCALE", "1"))):
         n = int(rng.choice([rng.integers(1, 600), rng.integers(600, 70000), rng.integers(70000, 400000)]))
         alpha = float(10.0 ** rng.uniform(-2.5, 1.0))
         k = int(rng.integers(1, 257))
