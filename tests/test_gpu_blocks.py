@@ -319,3 +319,83 @@ def test_seeded_random_pages_against_the_oracle(hf, orc):
         _, lens_h = orc.rp_system_codebook(f, 64, 0, 16)
         assert sys_.block_codebook(s, c)[2] == orc.rp_best_mode(f, lens_h)
     assert torch.equal(hf.ParrallelHuffmanDecoder().decode(s), t)
+
+
+def _random_counts(rng, cap):
+    """One 256-bin count vector with sum < cap: ties, zeros, skews and depths of every kind."""
+    kind = int(rng.integers(0, 6))
+    f = np.zeros(256, np.uint64)
+    if kind == 0:      # a sample of a Dirichlet distribution over k symbols
+        k = int(rng.integers(1, 257))
+        m = int(rng.integers(1, min(cap, 1 << 16)))
+        p = rng.dirichlet(np.full(k, float(10.0 ** rng.uniform(-2.5, 1.0))))
+        f[rng.permutation(256)[:k]] = rng.multinomial(m, p)
+    elif kind == 1:    # small integers: ties everywhere
+        f[:] = rng.integers(0, int(rng.integers(2, 200)), 256)
+    elif kind == 2:    # geometric with a random ratio: deep trees, the limiter works
+        r = float(rng.uniform(1.05, 2.2))
+        k = int(rng.integers(2, 257))
+        v = np.floor(r ** np.arange(k)).astype(np.float64)
+        v = v[np.cumsum(v) < cap / 2]
+        f[rng.permutation(256)[:v.size]] = v.astype(np.uint64)
+    elif kind == 3:    # Fibonacci weights: the deepest tree a sum allows
+        a, b, v = 1, 1, []
+        while sum(v) + a < cap / 2 and len(v) < 256:
+            v.append(a)
+            a, b = b, a + b
+        f[rng.permutation(256)[:len(v)]] = np.array(v, np.uint64)
+    elif kind == 4:    # a handful of symbols
+        k = int(rng.integers(1, 6))
+        f[rng.permutation(256)[:k]] = rng.integers(1, max(2, min(cap // 8, 1 << 30)), k)
+    else:              # flat with a few outliers
+        f[:] = int(rng.integers(1, 60))
+        f[rng.permutation(256)[:int(rng.integers(0, 9))]] = int(rng.integers(60, 4000))
+    assert int(f.sum()) < cap
+    return f
+
+
+def test_seeded_random_counts_against_the_oracle(hf, orc):
+    # count vectors that no 16384-symbol block produces (ties, zeros, Fibonacci and geometric
+    # weights, a random min_freq_threshold): the batched per-block codebooks (fast path below a sum
+    # of 2^16, general stages above) and the stream-wide codebook kernel (64-bit counts, the same
+    # vectors shifted up to 2^55) against the oracle
+    # (HF_SOAK_SEED / HF_SOAK_SCALE: another seed, and that many times the vectors, for a soak run)
+    import ctypes as C
+    from huffman_amd import _lib as L
+    rng = np.random.default_rng(int(os.environ.get("HF_SOAK_SEED", "4242")))
+    n_blocks = 96 * int(os.environ.get("HF_SOAK_SCALE", "1"))
+    ctx = hf.Context(0)
+    lib = L.lib()
+    sys_ = hf.EntropyAwareHuffmanSystem(ctx=ctx)
+    code = np.zeros(256, np.uint16)
+    lens = np.zeros(256, np.uint8)
+    mode, ent = C.c_int(0), C.c_uint32(0)
+    for thr in (0, int(rng.integers(1, 40))):
+        counts = np.stack([_random_counts(rng, (1 << 16) if c % 3 else (1 << 31))
+                           for c in range(n_blocks)])
+        d_freq = torch.from_numpy(counts.astype(np.uint32).view(np.int32).reshape(-1)).to(DEV)
+        d_cbs = torch.zeros(n_blocks * L.HF_CHUNK_CODEBOOK_BYTES, dtype=torch.uint8, device=DEV)
+        L.check(lib.hf_system_codebook_chunks_dev(ctx.handle, C.c_void_p(d_freq.data_ptr()),
+                                                  n_blocks, hf.HF_MODE_HUFFMAN, thr,
+                                                  C.c_void_p(d_cbs.data_ptr())), "codebooks")
+        for c in range(n_blocks):
+            L.check(lib.hf_chunk_codebook_download(
+                ctx.handle, C.c_void_p(d_cbs.data_ptr()), c,
+                code.ctypes.data_as(C.POINTER(C.c_uint16)),
+                lens.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(mode), C.byref(ent)), "download")
+            ecode, elens = orc.rp_system_codebook(counts[c], 64, thr, 16)
+            assert ent.value == orc.rp_entropy_q16_u64(counts[c]), (thr, c)
+            assert np.array_equal(lens, elens), (thr, c)
+            assert np.array_equal(code, ecode), (thr, c)
+        # the same vectors, shifted up as far as 2^55 allows, through the stream-wide kernel
+        for c in range(0, n_blocks, 4):
+            f = counts[c]
+            room = 55 - int(f.sum()).bit_length()
+            f = f << np.uint64(rng.integers(0, room + 1))
+            big_thr = thr << int(rng.integers(0, 20))
+            cb = sys_.codebook(torch.from_numpy(f.view(np.int64)).to(DEV), hf.HF_MODE_HUFFMAN,
+                               big_thr)
+            gcode, glens, _, gent = cb.download()
+            ecode, elens = orc.rp_system_codebook(f, 64, big_thr, 16)
+            assert gent == orc.rp_entropy_q16_u64(f), (thr, c)
+            assert np.array_equal(glens, elens) and np.array_equal(gcode, ecode), (thr, c)
