@@ -543,3 +543,43 @@ def test_two_contexts_on_two_streams_overlap(hf, orc):
         back = hf.ParrallelHuffmanDecoder(ctx=ctx).decode(st)
         ctx.sync()
         assert torch.equal(back.view(torch.uint8), data.view(torch.uint8))
+
+
+def test_seeded_random_module_calls_against_the_oracle(hf, orc):
+    # every module of the table stage at a random alphabet size 2..256, count magnitude, tie
+    # density and depth limit: SymbolSort, ShannonEntropy, HuffmanTreeBuilder (nodes, children,
+    # root, leaf depths), tree_adjust, EntropyAwareTreeBuilder -- all equal to the oracle's
+    # (HF_SOAK_SEED / HF_SOAK_SCALE: another seed, and that many times the cases, for a soak run)
+    rng = np.random.default_rng(int(os.environ.get("HF_SOAK_SEED", "1357")))
+    for case in range(80 * int(os.environ.get("HF_SOAK_SCALE", "1"))):
+        N = int(rng.choice([2, 3, 4, 5, 8, 16, rng.integers(2, 257), rng.integers(2, 257), 256]))
+        bits = int(rng.choice([1, 2, 4, 8, 16, 30, 44]))
+        f = rng.integers(0, 1 << bits, N).astype(np.uint64)
+        if rng.random() < 0.3:
+            f[rng.random(N) < rng.random()] = 0           # many zeros
+        if rng.random() < 0.2:
+            k = min(N, 60)
+            f[:] = 0
+            f[rng.permutation(N)[:k]] = (1 << np.arange(k).clip(max=40)).astype(np.uint64)  # deep
+        W = 64 if int(f.sum()) >= (1 << 32) - 1 else int(rng.choice([32, 64]))
+        srt = hf.SymbolSort(N, 64)
+        out = srt(f)
+        exp, ids = orc.aw_symbol_sort(f)
+        assert np.array_equal(out, exp) and np.array_equal(srt.rank2sym, ids), case
+        if N == 256:
+            assert hf.ShannonEntropy(256, 32)(f)[0] == orc.rp_entropy_q16_u64(f), case
+        t = hf.HuffmanTreeBuilder(N, W)(f)
+        o = orc.aw_tree_build(f, W)
+        for k in ("weights", "lefts", "rights"):
+            assert np.array_equal(t[k], o[k]), (case, k)
+        assert t["root"] == o["root"], case
+        depths = orc.rp_leaf_depths(o["lefts"], o["rights"], o["root"], N)
+        assert np.array_equal(t["depths"], depths), case
+        lo = max(1, int(np.ceil(np.log2(N))))
+        lmax = int(rng.integers(lo, 17))
+        assert np.array_equal(hf.tree_adjust(N, lmax)(depths), orc.rp_tree_adjust(depths, lmax)[0]), case
+        thr = int(rng.choice([0, 0, 1, int(rng.integers(1, 1 << bits))]))
+        code, lens = hf.EntropyAwareTreeBuilder(N, 64)(f, tree_depth_limit=lmax,
+                                                       min_freq_threshold=thr)
+        ec, el = orc.rp_codebook(f, 64, thr, lmax)
+        assert np.array_equal(code, ec) and np.array_equal(lens, el), (case, N, lmax, thr)
