@@ -325,7 +325,11 @@ constexpr int kWavesC = 4;
 constexpr int kTailEntries = 512;  // direct table for the long codes when their space fits
 
 // `tmp` (256 words) may alias the payload window: it is only used before the window is staged.
-__device__ void build_chunk_tables(const hf_chunk_cb* __restrict__ ccb, uint16_t* __restrict__ lut,
+// Returns false (wave-uniform), with nothing but cleared tables behind it, when the
+// record is not a canonical order: lengths of 1..16 that never decrease with the rank (a zero,
+// "symbol absent", only after them) and fill no more than the code space.  That is what keeps
+// every span below inside its table, so a damaged record cannot reach a neighbour's tables.
+__device__ bool build_chunk_tables(const hf_chunk_cb* __restrict__ ccb, uint16_t* __restrict__ lut,
                                    uint8_t* __restrict__ r2s, uint32_t* __restrict__ tmp,
                                    uint16_t* __restrict__ tail, ChunkTables& T, const int lane) {
     constexpr int B = ChunkTables::kBits;
@@ -353,6 +357,19 @@ __device__ void build_chunk_tables(const hf_chunk_cb* __restrict__ ccb, uint16_t
         if (lane >= o) incl += v;
     }
     const uint32_t lane_base = incl - lane_total;
+    bool valid;
+    {
+        const uint32_t before = __shfl_up(len[3], 1);
+        bool ok = incl <= 65536u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t a = i ? len[i - 1] : (lane ? before : 1u);
+            ok = ok && len[i] <= 16u && (len[i] == 0u || (a != 0u && a <= len[i]));
+        }
+        valid = __ballot(!ok) == 0ull;
+        // a refused record builds nothing: with every length cleared no span below is written
+        if (!valid) len[0] = len[1] = len[2] = len[3] = 0u;
+    }
     // blocks of the long codes: where each long length starts in the code space and the rank of
     // its first code.  Everything before them is the short codes taken together.
     uint32_t cnt_below = 0, short_width = 0;
@@ -440,6 +457,7 @@ __device__ void build_chunk_tables(const hf_chunk_cb* __restrict__ ccb, uint16_t
     T.lut = lut;
     T.rank2sym = r2s;
     T.tail = tail;
+    return valid;
 }
 
 template <int LAYOUT>
@@ -480,7 +498,11 @@ __global__ __launch_bounds__(kWavesC * 64) void hf_k_decode_chunks(
         }
         ChunkTables T;
         // (the fill descriptors of the build borrow the payload window, staged only afterwards)
-        build_chunk_tables(cbs + c, lut_all[wv], r2s_all[wv], stage[wv], tail_all[wv], T, lane);
+        if (!build_chunk_tables(cbs + c, lut_all[wv], r2s_all[wv], stage[wv], tail_all[wv], T,
+                                lane)) {
+            if (lane == 0) atomicOr(err, HF_KERR_CORRUPT);
+            continue;
+        }
         const uint8_t* side_chunk = side ? side + first : nullptr;
         const uint64_t out_first = chunk_ids ? (uint64_t)slot * HF_CHUNK_SYMS : first;
         void* out_chunk = reinterpret_cast<uint8_t*>(out) + out_first * elem_bytes;

@@ -214,7 +214,11 @@ int hf_encode_chunks(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
                      uint64_t payload_cap_words, uint32_t* d_chunk_off, uint64_t* h_total_words);
 /* as hf_decode.  d_chunk_ids == NULL: every chunk to its own place in d_out (n elements).
  * Otherwise decode-on-read: the n_ids listed chunks, in that order, to d_out + k * 16384
- * elements (all listed chunks must be full chunks; `n` still describes the encoded stream). */
+ * elements (all listed chunks must be full chunks; `n` still describes the encoded stream).
+ * A chunk whose record is not a canonical order (lengths above 16, decreasing with the rank, or
+ * filling more than the code space), whose offsets are out of order or past the payload, or whose
+ * id is out of range is left undecoded and HF_ERR_CORRUPT is returned (with check != 0); the
+ * other chunks of the call are decoded all the same. */
 int hf_decode_chunks(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
                      const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n, int layout,
                      const void* d_chunk_codebooks, const uint32_t* d_chunk_ids, uint64_t n_ids,

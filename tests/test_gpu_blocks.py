@@ -399,3 +399,36 @@ def test_seeded_random_counts_against_the_oracle(hf, orc):
             ecode, elens = orc.rp_system_codebook(f, 64, big_thr, 16)
             assert gent == orc.rp_entropy_q16_u64(f), (thr, c)
             assert np.array_equal(glens, elens) and np.array_equal(gcode, ecode), (thr, c)
+
+
+@pytest.mark.parametrize("damage", ["decreasing", "overfull", "too_long"])
+def test_damaged_page_record_is_reported_and_stays_contained(hf, damage):
+    # a page record whose lengths are not a canonical order (they decrease with the rank, fill
+    # more than the code space, or exceed 16) is refused by the decoder's table build: the call
+    # reports a corrupt stream, the page is left alone and every other page still decodes
+    rng = np.random.default_rng(3)
+    n_pages = 12
+    sym = np.minimum(rng.geometric(0.08, n_pages * CH) - 1, 255).astype(np.uint8)
+    t = torch.from_numpy(sym).to(DEV)
+    s = hf.EntropyAwareHuffmanSystem().encode_blocks(t, mode=hf.HF_MODE_HUFFMAN)
+    from huffman_amd import _lib as L
+    rec = s.chunk_codebooks.view(n_pages, L.HF_CHUNK_CODEBOOK_BYTES)
+    lens = rec[5, 1280:1536]  # len_by_rank of page 5
+    if damage == "decreasing":
+        lens[10], lens[200] = lens[200].clone(), lens[10].clone()
+    elif damage == "overfull":
+        lens[:] = 3
+    else:
+        lens[255] = 40
+    out = torch.full((n_pages * CH,), 0xEE, dtype=torch.uint8, device=DEV)
+    with pytest.raises(hf.HuffhipError) as ei:
+        hf.ParrallelHuffmanDecoder().decode_blocks(s, out=out)
+    assert ei.value.code == -7
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(n_pages, CH)
+    exp = sym.reshape(n_pages, CH)
+    for c in range(n_pages):
+        if c == 5:
+            assert np.all(got[c] == 0xEE)
+        else:
+            assert np.array_equal(got[c], exp[c]), c
