@@ -583,3 +583,31 @@ def test_seeded_random_module_calls_against_the_oracle(hf, orc):
                                                        min_freq_threshold=thr)
         ec, el = orc.rp_codebook(f, 64, thr, lmax)
         assert np.array_equal(code, ec) and np.array_equal(lens, el), (case, N, lmax, thr)
+
+
+@pytest.mark.parametrize("blocks", [False, True])
+def test_flipped_payload_bits_never_break_the_decoder(hf, blocks):
+    # random bit flips in the payload: the decoder's loops are counted, its reads clamped to the
+    # payload and its writes fixed by position, so the call ends with either a corrupt-stream
+    # report or wrong symbols in the right places -- and the context decodes the intact stream
+    # afterwards as if nothing had happened
+    rng = np.random.default_rng(8)
+    sym = np.minimum(rng.geometric(0.05, 20 * 16384 + 777) - 1, 255).astype(np.uint8)
+    t = dev_u8(sym)
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    dec = hf.ParrallelHuffmanDecoder(ctx=sys_.ctx)
+    s = sys_.encode_blocks(t, mode=hf.HF_MODE_HUFFMAN) if blocks else sys_.encode(t, mode=hf.HF_MODE_HUFFMAN)
+    run = dec.decode_blocks if blocks else dec.decode
+    good = s.payload.clone()
+    for trial in range(6):
+        s.payload.copy_(good)
+        words = torch.from_numpy(rng.integers(0, s.total_words, 64)).to(s.payload.device)
+        masks = torch.from_numpy((1 << rng.integers(0, 31, 64)).astype(np.int32)).to(s.payload.device)
+        s.payload[words] ^= masks
+        try:
+            out = run(s)
+            assert out.numel() == sym.size
+        except hf.HuffhipError as e:
+            assert e.code == -7
+    s.payload.copy_(good)
+    assert torch.equal(run(s), t)
