@@ -45,9 +45,10 @@ __device__ __forceinline__ void sort256_desc(T (&k)[4], const int lane) {
                 for (int i = 0; i < 4; ++i) {
                     const T o = __shfl_xor(k[i], lj);
                     const bool desc = (((lane * 4 + i) & kk) == 0);
-                    const T mx = k[i] > o ? k[i] : o;
-                    const T mn = k[i] > o ? o : k[i];
-                    k[i] = (lower == desc) ? mx : mn;
+                    // keep the larger where (lower == desc), the smaller elsewhere: the partner's
+                    // key is taken exactly when "mine is larger" and "keep the larger" disagree
+                    // (one compare, one mask operation, one select; keys are distinct)
+                    k[i] = ((k[i] > o) != (lower == desc)) ? o : k[i];
                 }
             } else {
 #pragma unroll
@@ -58,6 +59,69 @@ __device__ __forceinline__ void sort256_desc(T (&k)[4], const int lane) {
                         const bool sw = desc ? (a < b) : (a > b);
                         k[i] = sw ? b : a;
                         k[i | j] = sw ? a : b;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// The same network for 32-bit keys that are all distinct.  Which lanes keep the larger key of a
+// pair is a property of the lane number alone, so for every stage it is a 64-bit constant; the
+// compiler, to which the lane number is just a value, would recompute it per stage in vector
+// registers.  Here the constant sits in a scalar register pair and is folded into the compare's
+// result by one scalar instruction: two vector instructions per key and stage across lanes,
+// three per pair inside a lane.
+constexpr unsigned long long sort_keep_mask(const int kk, const int lj) {
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l)
+        if (((l & lj) == 0) == (((l * 4) & kk) == 0)) m |= 1ull << l;
+    return m;
+}
+constexpr unsigned long long sort_asc_mask(const int kk, const int i) {
+    unsigned long long m = 0;  // lanes whose element i sits in an ascending run of this phase
+    for (int l = 0; l < 64; ++l)
+        if (((l * 4 + i) & kk) != 0) m |= 1ull << l;
+    return m;
+}
+
+__device__ __forceinline__ void sort256_desc_u32(uint32_t (&k)[4], const int lane) {
+#pragma unroll
+    for (int kk = 2; kk <= 256; kk <<= 1) {
+#pragma unroll
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            if (j >= 4) {
+                const int lj = j >> 2;
+                const unsigned long long keep = sort_keep_mask(kk, lj);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t o = __shfl_xor(k[i], lj);
+                    uint32_t r;
+                    asm("v_cmp_gt_u32 vcc, %1, %2\n\t"
+                        "s_xor_b64 vcc, vcc, %3\n\t"
+                        "v_cndmask_b32 %0, %1, %2, vcc"
+                        : "=v"(r)
+                        : "v"(k[i]), "v"(o), "s"(keep)
+                        : "vcc", "scc");  // s_xor_b64 also writes SCC
+                    k[i] = r;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if ((i & j) == 0) {
+                        // descending run: swap when a < b; ascending run: when a > b, which for
+                        // distinct keys is the complement
+                        const unsigned long long asc = sort_asc_mask(kk, i);
+                        uint32_t na, nb;
+                        asm("v_cmp_lt_u32 vcc, %2, %3\n\t"
+                            "s_xor_b64 vcc, vcc, %4\n\t"
+                            "v_cndmask_b32 %0, %2, %3, vcc\n\t"
+                            "v_cndmask_b32 %1, %3, %2, vcc"
+                            : "=&v"(na), "=&v"(nb)
+                            : "v"(k[i]), "v"(k[i | j]), "s"(asc)
+                            : "vcc", "scc");  // s_xor_b64 also writes SCC
+                        k[i] = na;
+                        k[i | j] = nb;
                     }
                 }
             }
@@ -571,7 +635,7 @@ __global__ __launch_bounds__(64) void hf_k_chunks_front(const uint32_t* __restri
     uint32_t k[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) k[i] = (cnt[i] << 8) | (uint32_t)(255 - (lane * 4 + i));
-    sort256_desc(k, lane);  // (count desc, symbol asc); element e = lane * 4 + i
+    sort256_desc_u32(k, lane);  // (count desc, symbol asc); element e = lane * 4 + i
     uint32_t f[4];
     uint32_t r2s4 = 0;
 #pragma unroll
