@@ -43,3 +43,24 @@ def test_payload_of_more_than_2_32_words_is_refused(hf):
     with pytest.raises(hf.HuffhipError) as ei:
         sys_.encode(t, mode=hf.HF_MODE_BYPASS)
     assert ei.value.code == -5
+
+
+def test_counts_above_32_bits(hf, orc):
+    # 8.6e9 symbols of which all but a sprinkle are one value: a 64-bit count above 2^32 goes
+    # through the histogram, the entropy stage (counts shifted into 32 bits first), the tree and
+    # the encoder; the table must be the oracle's for the same counts and the stream round-trips
+    n = 8_600_000_000
+    t = torch.full((n,), 7, dtype=torch.uint8, device=DEV)
+    idx = torch.arange(0, n, 1_000_003, device=DEV)
+    t[idx] = (idx % 251).to(torch.uint8)
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    freq = sys_.histogram(t).cpu().numpy().astype(np.uint64)
+    exp = np.bincount((np.arange(0, n, 1_000_003) % 251).astype(np.int64), minlength=256).astype(np.uint64)
+    exp[7] += n - idx.numel()
+    assert np.array_equal(freq, exp) and int(freq[7]) > (1 << 32)
+    s = sys_.encode(t, mode=hf.HF_MODE_HUFFMAN)
+    code, lens, m, ent = s.codebook.download()
+    ec, el = orc.rp_system_codebook(freq, 64, 0, 16)
+    assert ent == orc.rp_entropy_q16_u64(freq)
+    assert np.array_equal(code, ec) and np.array_equal(lens, el)
+    assert torch.equal(hf.ParrallelHuffmanDecoder(ctx=sys_.ctx).decode(s), t)
