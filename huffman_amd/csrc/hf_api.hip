@@ -60,6 +60,16 @@ int kerr_to_code(uint32_t bits) {
     return HF_OK;
 }
 
+// In-kernel errors are sticky: the kernels OR their bits into d_ctl[1], and the word is cleared
+// only when it is reported -- by a call that synchronises, by hf_sync, or by hf_flush -- so that
+// the errors of calls that only enqueue work are not lost.  Expects the stream synchronised and
+// h_ctl holding a copy of d_ctl.
+int report_kernel_errors(hf_ctx* ctx) {
+    const uint32_t bits = ctx->h_ctl[1];
+    if (bits) HF_HIP(hipMemsetAsync(ctx->d_ctl + 1, 0, sizeof(uint32_t), ctx->stream));
+    return kerr_to_code(bits);
+}
+
 int use_device(hf_ctx* ctx) {
     HF_HIP(hipSetDevice(ctx->device));
     return HF_OK;
@@ -133,6 +143,7 @@ int hf_ctx_create(hf_ctx** out, int device, void* stream) {
     ok = ok && hipHostMalloc(&ctx->h_freq, 256 * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipMalloc(&ctx->d_ctl, 64) == hipSuccess;
     ok = ok && hipHostMalloc(&ctx->h_ctl, 64) == hipSuccess;
+    ok = ok && hipMemset(ctx->d_ctl, 0, 64) == hipSuccess;  // ticket and the sticky error word
     ok = ok && hipMalloc(&ctx->d_spill, hf_encode_spill_bytes(ctx->num_cu)) == hipSuccess;
     ok = ok && hipEventCreate(&ctx->ev0) == hipSuccess;
     ok = ok && hipEventCreate(&ctx->ev1) == hipSuccess;
@@ -168,8 +179,9 @@ int hf_ctx_destroy(hf_ctx* ctx) {
 int hf_sync(hf_ctx* ctx) {
     if (!ctx) return HF_ERR_ARG;
     if (int rc = use_device(ctx)) return rc;
+    HF_HIP(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl, 64, hipMemcpyDeviceToHost, ctx->stream));
     HF_HIP(hipStreamSynchronize(ctx->stream));
-    return HF_OK;
+    return report_kernel_errors(ctx);
 }
 
 int hf_flush(hf_ctx* ctx) {
@@ -461,7 +473,7 @@ static int encode_common(hf_ctx* ctx, const void* d_data, uint64_t n, int layout
         HF_HIP(hipMalloc(&ctx->d_desc, cap * sizeof(unsigned long long)));
         ctx->desc_cap = cap;
     }
-    HF_HIP(hipMemsetAsync(ctx->d_ctl, 0, 64, ctx->stream));
+    HF_HIP(hipMemsetAsync(ctx->d_ctl, 0, sizeof(uint32_t), ctx->stream));  // the ticket only
     if (nchunks == 0) {
         HF_HIP(hipMemsetAsync(d_chunk_off, 0, sizeof(uint32_t), ctx->stream));
     } else {
@@ -487,7 +499,7 @@ static int encode_common(hf_ctx* ctx, const void* d_data, uint64_t n, int layout
                               hipMemcpyDeviceToHost, ctx->stream));
         HF_HIP(hipStreamSynchronize(ctx->stream));
         *h_total_words = ctx->h_ctl[8];
-        return kerr_to_code(ctx->h_ctl[1]);
+        return report_kernel_errors(ctx);
     }
     return HF_OK;
 }
@@ -558,7 +570,6 @@ static int decode_chunks_common(hf_ctx* ctx, const uint32_t* d_payload, uint64_t
         return HF_ERR_ALIGN;
     if (n > (1ull << 40) || n_work > 0x7FFFFFFFull || n_slots > 0xFFFFFFFFull) return HF_ERR_RANGE;
     if (int rc = use_device(ctx)) return rc;
-    HF_HIP(hipMemsetAsync(ctx->d_ctl, 0, 64, ctx->stream));
     if (n_work) {
         tic(ctx);
         hf_launch_decode_chunks(d_payload, payload_words, d_chunk_off, d_side, n, lay,
@@ -571,7 +582,7 @@ static int decode_chunks_common(hf_ctx* ctx, const uint32_t* d_payload, uint64_t
     if (check) {
         HF_HIP(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl, 64, hipMemcpyDeviceToHost, ctx->stream));
         HF_HIP(hipStreamSynchronize(ctx->stream));
-        return kerr_to_code(ctx->h_ctl[1]);
+        return report_kernel_errors(ctx);
     }
     return HF_OK;
 }
@@ -627,7 +638,6 @@ int hf_decode(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
         return HF_ERR_ALIGN;
     if (n > (1ull << 40)) return HF_ERR_RANGE;
     if (int rc = use_device(ctx)) return rc;
-    HF_HIP(hipMemsetAsync(ctx->d_ctl, 0, 64, ctx->stream));
     if (n) {
         tic(ctx);
         hf_launch_decode(d_payload, payload_words, d_chunk_off, d_side, n, lay,
@@ -639,7 +649,7 @@ int hf_decode(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
     if (check) {
         HF_HIP(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl, 64, hipMemcpyDeviceToHost, ctx->stream));
         HF_HIP(hipStreamSynchronize(ctx->stream));
-        return kerr_to_code(ctx->h_ctl[1]);
+        return report_kernel_errors(ctx);
     }
     return HF_OK;
 }
@@ -838,14 +848,13 @@ int hf_container_codebook(hf_ctx* ctx, const void* d_blob, const hf_container_in
         HF_HIP(hipStreamSynchronize(ctx->stream));
         return HF_OK;
     }
-    HF_HIP(hipMemsetAsync(ctx->d_ctl, 0, 64, ctx->stream));
     hf_launch_wire_to_cb(reinterpret_cast<const hf_wire_chunk_cb*>(blob + pl.off_codebook),
                          pl.nchunks, reinterpret_cast<hf_chunk_cb*>(d_codebook_out),
                          ctx->d_ctl + 1, ctx->stream);
     HF_HIP(hipGetLastError());
     HF_HIP(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl, 64, hipMemcpyDeviceToHost, ctx->stream));
     HF_HIP(hipStreamSynchronize(ctx->stream));
-    return kerr_to_code(ctx->h_ctl[1]);
+    return report_kernel_errors(ctx);
 }
 
 /* ---- TreeQualityAnalyzer --------------------------------------------------------------------------

@@ -87,6 +87,9 @@ int hf_ctx_destroy(hf_ctx* ctx);
  * entropy_aware_tree_builder.scala:166-168, top_encoder.scala:178-183): drop any in-flight
  * block state; here: wait for the stream and clear the ctx's accumulators and error word. */
 int hf_flush(hf_ctx* ctx);
+/* Wait for the stream.  In-kernel errors (HF_ERR_OVERFLOW, HF_ERR_CORRUPT, HF_ERR_TIMEOUT) are
+ * sticky: a call that only enqueues work leaves them in the ctx, and the next call that
+ * synchronises -- hf_sync, or an encode / decode call asked to report -- returns and clears them. */
 int hf_sync(hf_ctx* ctx);
 const char* hf_error_string(int code);
 int hf_last_hip_error(hf_ctx* ctx);

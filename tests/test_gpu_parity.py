@@ -611,3 +611,23 @@ def test_flipped_payload_bits_never_break_the_decoder(hf, blocks):
             assert e.code == -7
     s.payload.copy_(good)
     assert torch.equal(run(s), t)
+
+
+def test_errors_of_enqueue_only_calls_are_kept_until_reported(hf):
+    # a decode that only enqueues work (check = 0) on a damaged stream leaves its error in the
+    # context; later enqueue-only calls do not wipe it, hf_sync reports it once and clears it
+    sym = skewed_symbols(50000, 2, "geometric")
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    dec = hf.ParrallelHuffmanDecoder(ctx=sys_.ctx)
+    s = sys_.encode(dev_u8(sym), mode=hf.HF_MODE_HUFFMAN)
+    good = int(s.chunk_off[1].item())
+    s.chunk_off[1] = 0x7FFFFFF0
+    dec.decode(s, check_stream=False)      # damaged, not reported yet
+    s.chunk_off[1] = good
+    out = dec.decode(s, check_stream=False)  # intact, enqueue only: must not clear the error
+    with pytest.raises(hf.HuffhipError) as ei:
+        sys_.ctx.sync()
+    assert ei.value.code == -7
+    sys_.ctx.sync()                          # reported once
+    assert np.array_equal(out.cpu().numpy(), sym)
+    assert np.array_equal(dec.decode(s).cpu().numpy(), sym)
