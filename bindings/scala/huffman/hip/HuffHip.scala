@@ -15,6 +15,7 @@ trait HuffHip extends Library {
   def hf_ctx_create(out: PointerByReference, device: Int, stream: Pointer): Int
   def hf_ctx_destroy(ctx: Pointer): Int
   def hf_flush(ctx: Pointer): Int                                   // every module's `flush`
+  def hf_sync(ctx: Pointer): Int     // wait for the stream; returns and clears kept kernel errors
   // SymbolStat.io: data_in -> freq_out (symbol_stat.scala:7-13)
   def hf_symbol_stat(ctx: Pointer, dData: Pointer, n: Long, layout: Int, depth: Int, wtWidth: Int,
                      hFreq: Array[Long]): Int
