@@ -8,7 +8,8 @@
 package huffman.hip
 
 import com.sun.jna.{Library, Native, Pointer, Structure}
-import com.sun.jna.ptr.{IntByReference, LongByReference, PointerByReference, ShortByReference}
+import com.sun.jna.ptr.{FloatByReference, IntByReference, LongByReference, PointerByReference,
+  ShortByReference}
 
 trait HuffHip extends Library {
   def hf_abi_version(): Int
@@ -16,6 +17,12 @@ trait HuffHip extends Library {
   def hf_ctx_destroy(ctx: Pointer): Int
   def hf_flush(ctx: Pointer): Int                                   // every module's `flush`
   def hf_sync(ctx: Pointer): Int     // wait for the stream; returns and clears kept kernel errors
+  def hf_error_string(code: Int): String
+  def hf_last_hip_error(ctx: Pointer): Int
+  def hf_num_chunks(n: Long): Long
+  def hf_payload_bound_words(n: Long): Long                         // worst case over all codebooks
+  def hf_set_timing(ctx: Pointer, enabled: Int): Int
+  def hf_last_kernel_ms(ctx: Pointer, ms: FloatByReference): Int    // device time of the last call
   // SymbolStat.io: data_in -> freq_out (symbol_stat.scala:7-13)
   def hf_symbol_stat(ctx: Pointer, dData: Pointer, n: Long, layout: Int, depth: Int, wtWidth: Int,
                      hFreq: Array[Long]): Int
