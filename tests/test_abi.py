@@ -133,3 +133,15 @@ def test_product_sources_never_touch_the_oracle():
                 if re.search(r"\boracle\b|liboracle|hf_oracle", txt):
                     bad.append(os.path.join(base, f))
     assert not bad, bad
+
+
+def test_scala_binding_names_every_entry_point():
+    # the JNA interface a maintainer of the reference would add (source only: no JVM here) must
+    # declare exactly the functions the header declares
+    import os
+    import re
+    from huffman_amd import _lib as L
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "bindings", "scala", "huffman", "hip", "HuffHip.scala")).read()
+    scala = set(re.findall(r"def (hf_[a-z0-9_]+)\(", text))
+    assert scala == set(L.SIGNATURES)
