@@ -101,14 +101,17 @@ __device__ __forceinline__ uint32_t decode_one(u64& win, int& room, const TAB& T
 }
 
 // Copy payload words [gs, gs + W) into the wavefront's LDS window; gs is a multiple of 4 so
-// every access is a 16-byte one.  Words past the payload buffer read as zero.
+// every access is a 16-byte one.  A well-formed chunk consumes no word at or past its end
+// `off1`, so the loads of the window's part behind the chunk's last 16-byte group are redirected
+// to that group (as are loads past the buffer, to its last 16 bytes): all loads are issued back
+// to back without branches, and the redirected ones fall on one line and move no further bytes.
 template <int W>
 __device__ __forceinline__ void stage_window(const uint32_t* __restrict__ payload,
-                                             const u64 payload_words, const u64 gs,
+                                             const u64 payload_words, const u64 off1, const u64 gs,
                                              uint32_t* __restrict__ stg, const int lane) {
-    // Loads past the buffer are redirected to its last 16 bytes (a well-formed chunk never
-    // consumes those words), so all eight loads are issued back to back without branches.
-    const u64 last = (payload_words - 4) & ~3ull;  // the caller guarantees payload_words >= 4
+    const u64 last_buf = (payload_words - 4) & ~3ull;  // the caller guarantees payload_words >= 4
+    const u64 last_chunk = (off1 ? off1 - 1 : 0) & ~3ull;
+    const u64 last = last_chunk < last_buf ? last_chunk : last_buf;
     uint4 v[W / 256];
 #pragma unroll
     for (int k = 0; k < W / 256; ++k) {
@@ -151,7 +154,7 @@ __device__ u64 decode_chunk_full(const uint32_t* __restrict__ payload, const u64
                                  void* __restrict__ out_chunk, const TAB& T,
                                  uint32_t* __restrict__ stg, uint32_t* err, const int lane) {
     u64 gs = off0 & ~3ull;
-    stage_window<TAB::kStage>(payload, payload_words, gs, stg, lane);
+    stage_window<TAB::kStage>(payload, payload_words, off1, gs, stg, lane);
     uint32_t lpos = (uint32_t)(off0 - gs);  // window index of the next unread word
     u64 win = 0;                            // buffered bits, MSB aligned
     int room = 32;                          // 32 - buffered bit count
@@ -173,7 +176,7 @@ __device__ u64 decode_chunk_full(const uint32_t* __restrict__ payload, const u64
         if (lpos + 256u > (uint32_t)TAB::kStage && gs + TAB::kStage < off1) {
             gs = (gs + lpos) & ~3ull;
             lpos = lpos & 3u;
-            stage_window<TAB::kStage>(payload, payload_words, gs, stg, lane);
+            stage_window<TAB::kStage>(payload, payload_words, off1, gs, stg, lane);
         }
         uint32_t e[8];  // table entries: symbol in byte 1
 #pragma unroll
@@ -229,7 +232,7 @@ __device__ u64 decode_chunk_tail(const uint32_t* __restrict__ payload, const u64
                                  const TAB& T, uint32_t* __restrict__ stg, uint32_t* err,
                                  const int lane) {
     u64 gs = off0 & ~3ull;
-    stage_window<TAB::kStage>(payload, payload_words, gs, stg, lane);
+    stage_window<TAB::kStage>(payload, payload_words, off1, gs, stg, lane);
     uint32_t lpos = (uint32_t)(off0 - gs);
     u64 win = 0;
     int room = 32;
@@ -239,7 +242,7 @@ __device__ u64 decode_chunk_tail(const uint32_t* __restrict__ payload, const u64
         if (lpos + 256u > (uint32_t)TAB::kStage && gs + TAB::kStage < off1) {
             gs = (gs + lpos) & ~3ull;
             lpos = lpos & 3u;
-            stage_window<TAB::kStage>(payload, payload_words, gs, stg, lane);
+            stage_window<TAB::kStage>(payload, payload_words, off1, gs, stg, lane);
         }
         uint32_t s[8];
 #pragma unroll
