@@ -147,6 +147,26 @@ __device__ __forceinline__ void load_group(const void* chunk_in, const uint32_t 
     }
 }
 
+// The encoder table by LDS byte address: `tab` is the table's address (a multiple of 1024, wave-
+// uniform), `x` a value whose bits 2..9 are the symbol.  Address = (x & 0x3FC) | tab is a single
+// v_and_or_b32; through a pointer the compiler adds the table's base to the masked index even
+// when that base is zero.
+typedef __attribute__((address_space(3))) const uint32_t hf_lds_u32;
+__device__ __forceinline__ uint32_t enc_lookup(const uint32_t tab, const uint32_t x) {
+    uint32_t a;
+    if (__builtin_constant_p(tab) && tab == 0u) {
+        a = x & 0x3FCu;
+    } else {
+        // spelled out: the compiler makes an AND and an OR of it (the mask is a literal and the
+        // table address a scalar, one scalar operand too many for a single instruction)
+        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(a) : "v"(x), "s"(0x3FCu), "v"(tab));
+    }
+    return *reinterpret_cast<hf_lds_u32*>((uintptr_t)a);
+}
+__device__ __forceinline__ uint32_t lds_address(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
 // Per-lane packing state of one chunk.
 struct LaneState {
     u64 acc = 0;          // code bits not yet emitted, LSB aligned
@@ -182,17 +202,17 @@ __device__ __forceinline__ void put_word(const bool done, const uint32_t slot, c
 template <int LAYOUT, bool FULL, bool CHECK>
 __device__ __forceinline__ void encode_round(const uint32_t (&raw)[4], const uint32_t g,
                                              const uint32_t nvalid, LaneState& st,
-                                             const uint32_t* __restrict__ enc,
+                                             const uint32_t enc,
                                              uint32_t* __restrict__ stg,
                                              uint32_t* __restrict__ spill, const uint32_t limit,
                                              uint8_t* side_chunk, hf_gmem_u8* side_row) {
-    uint32_t s[8];
+    uint32_t s4[8];  // the symbols, times four, in bits 2..9 (higher bits: don't care)
     if (LAYOUT == HF_LAYOUT_BF16_EXP) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t d = raw[i];
-            s[2 * i] = (d >> 7) & 0xFFu;
-            s[2 * i + 1] = (d >> 23) & 0xFFu;
+            s4[2 * i] = d >> 5;
+            s4[2 * i + 1] = d >> 21;
         }
         // side bytes of four elements at once: v_perm_b32 gathers their low bytes (mantissa
         // under the exponent's last bit) and their high bytes (sign over exponent bits), one
@@ -217,12 +237,15 @@ __device__ __forceinline__ void encode_round(const uint32_t (&raw)[4], const uin
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s[i] = (raw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+        for (int i = 0; i < 8; ++i) {
+            const int sh = 8 * (i & 3) - 2;
+            s4[i] = sh < 0 ? raw[i >> 2] << 2 : raw[i >> 2] >> sh;
+        }
     }
 
     uint32_t e[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) e[i] = enc[s[i]];
+    for (int i = 0; i < 8; ++i) e[i] = enc_lookup(enc, s4[i]);
 
 #pragma unroll
     for (int jp = 0; jp < 4; ++jp) {
@@ -297,7 +320,7 @@ __device__ __forceinline__ void preload_chunk(const void* chunk_in, const int la
 // `buf` holds (or has loads in flight for) the first kDepth rounds when FULL.
 template <int LAYOUT, bool FULL>
 __device__ __forceinline__ uint32_t encode_chunk(const void* chunk_in, const uint32_t nvalid,
-                                 const uint32_t* __restrict__ enc, uint32_t* __restrict__ stg,
+                                 const uint32_t enc, uint32_t* __restrict__ stg,
                                  uint32_t* __restrict__ spill, const uint32_t limit,
                                  uint8_t* side_chunk, const int lane,
                                  uint32_t (&buf)[kDepth][4]) {
@@ -426,6 +449,13 @@ hf_k_encode(const void* __restrict__ data, const uint64_t n, const uint32_t nchu
     const uint32_t lag = pipelined ? 1u : 0u;
     const uint32_t limit = pipelined ? (uint32_t)kHalfWords : (uint32_t)kStgWords;
     uint32_t* enc = PER_CHUNK ? L.enc + ew * 256 : L.enc;
+    // the table's LDS address, wave-uniform; enc_lookup needs it to be a multiple of 1024
+    const uint32_t enc_tab = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(enc));
+    if ((enc_tab & 1023u) != 0 || (!PER_CHUNK && enc_tab != 0)) {
+        // (the same in every wavefront: the whole grid leaves)
+        if (threadIdx.x == 0) atomicOr(err, HF_KERR_CORRUPT);
+        return;
+    }
     uint32_t* spill_w = spill_base + ((size_t)blockIdx.x * kWaves + ew) * 2 * kSpillWords;
     const size_t elem_bytes = LAYOUT == HF_LAYOUT_BF16_EXP ? 2 : 1;
 
@@ -463,11 +493,11 @@ hf_k_encode(const void* __restrict__ data, const uint64_t n, const uint32_t nchu
                 uint32_t buf[kDepth][4];
                 if (nvalid == HF_CHUNK_SYMS) {
                     preload_chunk<LAYOUT>(chunk_in, lane, buf);
-                    total = encode_chunk<LAYOUT, true>(chunk_in, nvalid, enc, stg, spill, limit,
-                                                       side_chunk, lane, buf);
+                    total = encode_chunk<LAYOUT, true>(chunk_in, nvalid, PER_CHUNK ? enc_tab : 0u,
+                                                       stg, spill, limit, side_chunk, lane, buf);
                 } else {
-                    total = encode_chunk<LAYOUT, false>(chunk_in, nvalid, enc, stg, spill, limit,
-                                                        side_chunk, lane, buf);
+                    total = encode_chunk<LAYOUT, false>(chunk_in, nvalid, PER_CHUNK ? enc_tab : 0u,
+                                                        stg, spill, limit, side_chunk, lane, buf);
                 }
                 total = __builtin_amdgcn_readfirstlane(total);
             }
