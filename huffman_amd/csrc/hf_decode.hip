@@ -106,13 +106,13 @@ __device__ __forceinline__ uint32_t decode_one(u64& win, int& room, const TAB& T
 // to that group (as are loads past the buffer, to its last 16 bytes): all loads are issued back
 // to back without branches, and the redirected ones fall on one line and move no further bytes.
 template <int W>
-__device__ __forceinline__ void stage_window(const uint32_t* __restrict__ payload,
-                                             const u64 payload_words, const u64 off1, const u64 gs,
-                                             uint32_t* __restrict__ stg, const int lane) {
+__device__ __forceinline__ void stage_window_load(const uint32_t* __restrict__ payload,
+                                                  const u64 payload_words, const u64 off1,
+                                                  const u64 gs, const int lane,
+                                                  uint4 (&v)[W / 256]) {
     const u64 last_buf = (payload_words - 4) & ~3ull;  // the caller guarantees payload_words >= 4
     const u64 last_chunk = (off1 ? off1 - 1 : 0) & ~3ull;
     const u64 last = last_chunk < last_buf ? last_chunk : last_buf;
-    uint4 v[W / 256];
 #pragma unroll
     for (int k = 0; k < W / 256; ++k) {
         u64 idx = gs + (u64)(k * 256 + lane * 4);
@@ -120,9 +120,21 @@ __device__ __forceinline__ void stage_window(const uint32_t* __restrict__ payloa
         const hf_u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const hf_u32x4*>(payload + idx));
         v[k] = make_uint4(t.x, t.y, t.z, t.w);
     }
+}
+template <int W>
+__device__ __forceinline__ void stage_window_store(uint32_t* __restrict__ stg, const int lane,
+                                                   const uint4 (&v)[W / 256]) {
 #pragma unroll
     for (int k = 0; k < W / 256; ++k)
         *reinterpret_cast<uint4*>(stg + k * 256 + lane * 4) = v[k];
+}
+template <int W>
+__device__ __forceinline__ void stage_window(const uint32_t* __restrict__ payload,
+                                             const u64 payload_words, const u64 off1, const u64 gs,
+                                             uint32_t* __restrict__ stg, const int lane) {
+    uint4 v[W / 256];
+    stage_window_load<W>(payload, payload_words, off1, gs, lane, v);
+    stage_window_store<W>(stg, lane, v);
 }
 
 // refill step shared by both paths: lanes in `need` take consecutive words from the window
@@ -152,9 +164,11 @@ __device__ u64 decode_chunk_full(const uint32_t* __restrict__ payload, const u64
                                  const u64 off0, const u64 off1,
                                  const uint8_t* __restrict__ side_chunk,
                                  void* __restrict__ out_chunk, const TAB& T,
-                                 uint32_t* __restrict__ stg, uint32_t* err, const int lane) {
+                                 uint32_t* __restrict__ stg, uint32_t* err, const int lane,
+                                 const bool staged = false) {
     u64 gs = off0 & ~3ull;
-    stage_window<TAB::kStage>(payload, payload_words, off1, gs, stg, lane);
+    // (`staged`, wave-uniform: the caller has put the first window in place already)
+    if (!staged) stage_window<TAB::kStage>(payload, payload_words, off1, gs, stg, lane);
     uint32_t lpos = (uint32_t)(off0 - gs);  // window index of the next unread word
     u64 win = 0;                            // buffered bits, MSB aligned
     int room = 32;                          // 32 - buffered bit count
@@ -230,9 +244,9 @@ __device__ u64 decode_chunk_tail(const uint32_t* __restrict__ payload, const u64
                                  const uint8_t* __restrict__ side_chunk,
                                  void* __restrict__ out_chunk, const uint32_t nvalid,
                                  const TAB& T, uint32_t* __restrict__ stg, uint32_t* err,
-                                 const int lane) {
+                                 const int lane, const bool staged = false) {
     u64 gs = off0 & ~3ull;
-    stage_window<TAB::kStage>(payload, payload_words, off1, gs, stg, lane);
+    if (!staged) stage_window<TAB::kStage>(payload, payload_words, off1, gs, stg, lane);
     uint32_t lpos = (uint32_t)(off0 - gs);
     u64 win = 0;
     int room = 32;
@@ -277,21 +291,35 @@ __global__ __launch_bounds__(kWaves * 64) void hf_k_decode(
     uint32_t* err) {
     __shared__ __attribute__((aligned(16))) DecTables T;
     __shared__ __attribute__((aligned(16))) uint32_t stage[kWaves][kStageWords + kStageSlack];
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(cb->lut);
-        uint4* dst = reinterpret_cast<uint4*>(T.lut);
-        for (int i = threadIdx.x; i < (int)(HF_LUT_SIZE * 2 / 16); i += kWaves * 64) dst[i] = src[i];
-        const uint32_t nsub = cb->n_sub < 256u ? cb->n_sub : 256u;
-        const uint4* src2 = reinterpret_cast<const uint4*>(cb->sub);
-        uint4* dst2 = reinterpret_cast<uint4*>(T.sub);
-        for (uint32_t i = threadIdx.x; i < nsub * 2; i += kWaves * 64) dst2[i] = src2[i];
-    }
-    __syncthreads();
     const int lane = hf_lane();
     const int wv = threadIdx.x >> 6;
     uint32_t* stg = stage[wv];
     const uint32_t wave = blockIdx.x * kWaves + wv;
     const uint32_t nwaves = gridDim.x * kWaves;
+    // A workgroup lives for one chunk per wavefront, so what it waits for at its start counts.
+    // Everything it needs is requested in one go, without a branch in between: the chunk's
+    // offsets first (the window's addresses depend on them), the first-level table (one 16-byte
+    // piece per thread), the number of second-level tables, then the chunk's first payload window
+    // and the second-level tables in use; the LDS stores and the barrier follow.  Two memory
+    // round trips instead of five.
+    static_assert(kWaves * 64 * 16 == HF_LUT_SIZE * 2, "one 16-byte piece of the table per thread");
+    const uint32_t cw = wave < nchunks ? wave : nchunks - 1u;  // (nchunks >= 1)
+    const uint32_t o0 = __builtin_amdgcn_readfirstlane(chunk_off[cw]);
+    const uint32_t o1 = __builtin_amdgcn_readfirstlane(chunk_off[cw + 1]);
+    const uint4 t_lut = reinterpret_cast<const uint4*>(cb->lut)[threadIdx.x];
+    const uint32_t nsub = cb->n_sub < 256u ? cb->n_sub : 256u;
+    bool staged = wave < nchunks && o1 >= o0 && (uint64_t)o1 <= payload_words;
+    uint4 w[kStageWords / 256];
+    stage_window_load<kStageWords>(payload, payload_words, staged ? o1 : 0u,
+                                   staged ? (u64)o0 & ~3ull : 0ull, lane, w);
+    const bool has_sub = threadIdx.x < nsub * 2;  // 16 entries = two 16-byte pieces per table
+    const uint4 t_sub = reinterpret_cast<const uint4*>(cb->sub)[has_sub ? threadIdx.x : 0];
+    reinterpret_cast<uint4*>(T.lut)[threadIdx.x] = t_lut;
+    // (stored by every thread, so that the compiler keeps the load up there with the others:
+    // a second-level table no first-level entry names is never read, whatever it holds)
+    reinterpret_cast<uint4*>(T.sub)[threadIdx.x] = t_sub;
+    stage_window_store<kStageWords>(stg, lane, w);  // (likewise; unused when !staged)
+    __syncthreads();
     const size_t elem_bytes = LAYOUT == HF_LAYOUT_BF16_EXP ? 2 : 1;
     for (uint32_t c = wave; c < nchunks; c += nwaves) {
         const uint32_t off0 = __builtin_amdgcn_readfirstlane(chunk_off[c]);
@@ -300,6 +328,7 @@ __global__ __launch_bounds__(kWaves * 64) void hf_k_decode(
         const bool sane = off1 >= off0 && (uint64_t)off1 <= payload_words;
         if (!sane) {
             if (lane == 0) atomicOr(err, HF_KERR_CORRUPT);
+            staged = false;
             continue;
         }
         const uint64_t first = (uint64_t)c * HF_CHUNK_SYMS;
@@ -310,10 +339,11 @@ __global__ __launch_bounds__(kWaves * 64) void hf_k_decode(
         u64 end;
         if (nvalid == HF_CHUNK_SYMS)
             end = decode_chunk_full<LAYOUT>(payload, payload_words, off0, off1, side_chunk,
-                                            out_chunk, T, stg, err, lane);
+                                            out_chunk, T, stg, err, lane, staged);
         else
             end = decode_chunk_tail<LAYOUT>(payload, payload_words, off0, off1, side_chunk,
-                                            out_chunk, nvalid, T, stg, err, lane);
+                                            out_chunk, nvalid, T, stg, err, lane, staged);
+        staged = false;  // only the wavefront's first chunk was staged ahead
         // a well-formed chunk is consumed exactly
         if (end != off1 && lane == 0) atomicOr(err, HF_KERR_CORRUPT);
     }
