@@ -530,22 +530,27 @@ __global__ __launch_bounds__(kWavesC * 64) void hf_k_decode_chunks(
             continue;
         }
         ChunkTables T;
-        // (the fill descriptors of the build borrow the payload window, staged only afterwards)
+        // The first payload window is requested before the tables are built, so that the record's
+        // and the window's loads are in flight together; it goes to LDS only afterwards, because
+        // the fill descriptors of the build borrow the window's place.
+        uint4 w0[kStageWordsC / 256];
+        stage_window_load<kStageWordsC>(payload, payload_words, off1, (u64)off0 & ~3ull, lane, w0);
         if (!build_chunk_tables(cbs + c, lut_all[wv], r2s_all[wv], stage[wv], tail_all[wv], T,
                                 lane)) {
             if (lane == 0) atomicOr(err, HF_KERR_CORRUPT);
             continue;
         }
+        stage_window_store<kStageWordsC>(stage[wv], lane, w0);
         const uint8_t* side_chunk = side ? side + first : nullptr;
         const uint64_t out_first = chunk_ids ? (uint64_t)slot * HF_CHUNK_SYMS : first;
         void* out_chunk = reinterpret_cast<uint8_t*>(out) + out_first * elem_bytes;
         u64 end;
         if (nvalid == HF_CHUNK_SYMS)
             end = decode_chunk_full<LAYOUT>(payload, payload_words, off0, off1, side_chunk,
-                                            out_chunk, T, stage[wv], err, lane);
+                                            out_chunk, T, stage[wv], err, lane, true);
         else
             end = decode_chunk_tail<LAYOUT>(payload, payload_words, off0, off1, side_chunk,
-                                            out_chunk, nvalid, T, stage[wv], err, lane);
+                                            out_chunk, nvalid, T, stage[wv], err, lane, true);
         if (end != off1 && lane == 0) atomicOr(err, HF_KERR_CORRUPT);
         // the tables are rebuilt for the next chunk: all reads of this one are done
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
