@@ -6,7 +6,9 @@ One step = one pass of the hot path over the whole tensor, inputs resident in HB
     SymbolStat (histogram) -> [all-reduce of the 256 counts when N > 1: global codebook]
     -> sort/entropy/tree/adjust/canonical codes -> encode -> decode.
 `value` = uncompressed bytes through that round trip per second, summed over all ranks.
-Run as `python bench.py --gpus 1` or under torch.distributed.run with one rank per GPU.
+Run as `python bench.py --gpus N`: for N > 1 the script starts one rank per GPU itself (through
+torch.distributed.run, before anything touches a GPU) unless it already runs under such a
+launcher (WORLD_SIZE set), and rank 0 prints the one JSON line.
 """
 import argparse
 import glob
@@ -127,6 +129,29 @@ def pmc_traffic(n):
     return {}, None
 
 
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n_ranks):
+    """`bench.py --gpus N` run directly: start N ranks of this script as child processes and pass
+    their output through.  Nothing in this process has touched a GPU (torch is not even imported
+    yet), the children are fresh interpreters, and this process only waits for them."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,6 +163,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
     from huffman_amd import api as hf
@@ -145,26 +173,48 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run, one rank per GPU")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # HF_BENCH_BACKEND=gloo is a rehearsal of the N-rank flow on a box with fewer GPUs than ranks:
+    # ranks share the GPUs there are and the 256 counts are summed through host memory.  RCCL
+    # itself wants one GPU per rank, which is what the default (nccl) asks for.
+    backend = os.environ.get("HF_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py needs a GPU: no HIP device is visible")
+    if backend == "nccl" and local_rank >= ndev:
+        raise SystemExit(f"--gpus {args.gpus} needs {args.gpus} GPUs, this box shows {ndev}")
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     # HF_BENCH_FORCE_DIST=1 takes the multi-rank code path (process group, all-reduce, barriers)
     # with a single rank, to rehearse it on a one-GPU box
     use_dist = world > 1 or os.environ.get("HF_BENCH_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if world == 1:
-            dist.init_process_group("nccl", device_id=device, rank=0, world_size=1)
+        kw = dict(rank=rank, world_size=world)
+        if backend == "nccl":
+            kw["device_id"] = device
+        dist.init_process_group(backend, **kw)
+
+    def allreduce_counts(freq):
+        if backend == "nccl":
+            dist.all_reduce(freq)  # RCCL over xGMI, 2 KiB
         else:
-            dist.init_process_group("nccl", device_id=device)
+            host = freq.cpu()
+            dist.all_reduce(host)
+            freq.copy_(host)
+
+    def barrier():
+        if backend == "nccl":
+            dist.barrier(device_ids=[dev_index])
+        else:
+            dist.barrier()
 
     n = args.elems
     w = make_weights(torch, n, device)
-    ctx = hf.Context(local_rank)
+    ctx = hf.Context(dev_index)
     system = hf.EntropyAwareHuffmanSystem(ctx=ctx)
     decoder = hf.ParrallelHuffmanDecoder(ctx=ctx)
     stat = hf.SymbolStat(ctx=ctx)
@@ -183,7 +233,7 @@ def main():
         stat.accumulate(w, freq)
         if ev: ev[1].record()
         if use_dist:
-            dist.all_reduce(freq)  # global codebook: identical tables on every rank
+            allreduce_counts(freq)  # global codebook: identical tables on every rank
         system.codebook(freq, hf.HF_MODE_HUFFMAN, out=cb)
         if ev: ev[2].record()
         s = system.encode_with(w, cb, payload=payload, side=side, chunk_off=chunk_off, sync=False)
@@ -196,7 +246,7 @@ def main():
         s = step()
     torch.cuda.synchronize()
     if use_dist:
-        dist.barrier()
+        barrier()
     torch.cuda.synchronize()
 
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
@@ -205,11 +255,12 @@ def main():
         s = step(evs[k])
     torch.cuda.synchronize()
     if use_dist:
-        dist.barrier()
+        barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -272,7 +323,9 @@ def main():
                              f"{n} elements per GPU ({raw_bytes / 1e9:.2f} GB), exponent-byte "
                              "Huffman, forced Huffman mode, Lmax=16, 16384-symbol chunks"
                              + (", global codebook via RCCL all-reduce of the histogram"
-                                if world > 1 else "")),
+                                if world > 1 and backend == "nccl" else "")
+                             + (", REHEARSAL: ranks share GPUs, counts summed over gloo"
+                                if backend != "nccl" else "")),
                 "elements_per_gpu": n, "chunk_symbols": hf.HF_CHUNK_SYMS,
             },
             "encode_GBps": raw_bytes / ((ms["hist"] + ms["codebook"] + ms["encode"]) * 1e-3) / 1e9,
@@ -293,7 +346,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(torch, w, args.cpu_sample)
         print(json.dumps(line), flush=True)
     if use_dist:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
     if not ok:
         raise SystemExit("round trip mismatch")

@@ -50,7 +50,18 @@ def layout_of(t: torch.Tensor) -> int:
 
 
 def _dev_ptr(t: Optional[torch.Tensor]) -> int:
-    return 0 if t is None else t.data_ptr()
+    """Device address of a tensor the library will read or write as one flat array."""
+    if t is None:
+        return 0
+    if not t.is_contiguous():
+        raise ValueError("the library walks memory from data_ptr(): pass a contiguous tensor "
+                         "(inputs: .contiguous(); outputs cannot be strided views)")
+    return t.data_ptr()
+
+
+def _payload_words_default(n: int, nch: int) -> int:
+    """Room for 8 bits per symbol plus the per-lane look-ahead words."""
+    return max(4, n // 4 + nch * 192 + 64)
 
 
 class Context:
@@ -133,6 +144,7 @@ class SymbolStat(_Module):
 
     def __call__(self, data_in: torch.Tensor, layout: Optional[int] = None) -> np.ndarray:
         lay = layout_of(data_in) if layout is None else layout
+        data_in = data_in.contiguous()
         freq = np.zeros(self.depth, np.uint64)
         check(L.lib().hf_symbol_stat(self.ctx.handle, C.c_void_p(_dev_ptr(data_in)),
                                      data_in.numel(), lay, self.depth, self.wtWidth,
@@ -143,9 +155,10 @@ class SymbolStat(_Module):
                    layout: Optional[int] = None) -> None:
         """Device-side block: add the counts of ``data_in`` into ``freq256`` (int64[256])."""
         lay = layout_of(data_in) if layout is None else layout
+        data_in = data_in.contiguous()
         assert freq256.dtype == torch.int64 and freq256.numel() == 256 and freq256.is_cuda
         check(L.lib().hf_symbol_stat_dev(self.ctx.handle, C.c_void_p(_dev_ptr(data_in)),
-                                         data_in.numel(), lay, C.c_void_p(freq256.data_ptr())),
+                                         data_in.numel(), lay, C.c_void_p(_dev_ptr(freq256))),
               "hf_symbol_stat_dev")
 
 
@@ -362,11 +375,13 @@ class EncodedStream:
 
     def compressed_bytes(self) -> int:
         """payload + side stream + chunk offsets + codebooks.  A stream-wide codebook counts as
-        256 x (16-bit code, 8-bit length); a per-block codebook as its canonical order
-        (256 symbol ids + 17 length counts = 273 bytes per block)."""
+        256 x (16-bit code, 8-bit length); a per-block codebook as its record in the container
+        (HF_CONTAINER_CHUNK_CODEBOOK_BYTES = 296 bytes per block: 256 symbol ids, 16 length
+        counts, mode, entropy).  Section padding and the header are left to container_bytes()."""
         assert self.total_words is not None
         side = self.n if self.side is not None else 0
-        books = 256 * 3 if self.chunk_codebooks is None else 273 * self.nchunks
+        books = 256 * 3 if self.chunk_codebooks is None \
+            else L.HF_CONTAINER_CHUNK_CODEBOOK_BYTES * self.nchunks
         return 4 * self.total_words + side + 4 * (self.nchunks + 1) + books
 
     def ratio(self) -> float:
@@ -453,7 +468,9 @@ class EntropyAwareHuffmanSystem(_Module):
     def histogram(self, data_in: torch.Tensor, layout: Optional[int] = None,
                   freq256: Optional[torch.Tensor] = None) -> torch.Tensor:
         if freq256 is None:
-            freq256 = torch.zeros(256, dtype=torch.int64, device=data_in.device)
+            # cleared on the context's stream, where the kernel that adds into it runs
+            with torch.cuda.stream(self.ctx.stream):
+                freq256 = torch.zeros(256, dtype=torch.int64, device=data_in.device)
         SymbolStat(ctx=self.ctx).accumulate(data_in, freq256, layout)
         return freq256
 
@@ -470,23 +487,34 @@ class EntropyAwareHuffmanSystem(_Module):
                     payload: Optional[torch.Tensor] = None, side: Optional[torch.Tensor] = None,
                     chunk_off: Optional[torch.Tensor] = None, sync: bool = True) -> EncodedStream:
         lay = layout_of(data_in) if layout is None else layout
+        data_in = data_in.contiguous()
         n = data_in.numel()
         dev = data_in.device
         nch = (n + HF_CHUNK_SYMS - 1) // HF_CHUNK_SYMS
-        if payload is None:
-            # room for 8 bits/symbol plus the per-lane look-ahead words; worst case is larger
-            # (hf_payload_bound_words) and is reported as HF_ERR_OVERFLOW, never overrun
-            payload = torch.empty(max(4, n // 4 + nch * 192 + 64), dtype=torch.int32, device=dev)
+        own_payload = payload is None
+        if own_payload:
+            # a codebook built from other counts than this tensor's (a global or foreign table,
+            # a frequency threshold) can pass 8 bits per symbol: that is reported as
+            # HF_ERR_OVERFLOW, never overrun, and answered below with the worst-case size
+            payload = torch.empty(_payload_words_default(n, nch), dtype=torch.int32, device=dev)
         if chunk_off is None:
             chunk_off = torch.empty(((nch + 1 + 3) // 4) * 4, dtype=torch.int32, device=dev)
         if lay == HF_LAYOUT_BF16_EXP and side is None:
             side = torch.empty(max(16, n), dtype=torch.uint8, device=dev)
         total = C.c_uint64(0)
-        check(L.lib().hf_encode(self.ctx.handle, C.c_void_p(_dev_ptr(data_in)), n, lay,
-                                C.c_void_p(cb.ptr), C.c_void_p(_dev_ptr(side)),
-                                C.c_void_p(payload.data_ptr()), payload.numel(),
-                                C.c_void_p(chunk_off.data_ptr()),
-                                C.byref(total) if sync else None), "hf_encode")
+
+        def run(buf):
+            return L.lib().hf_encode(self.ctx.handle, C.c_void_p(_dev_ptr(data_in)), n, lay,
+                                     C.c_void_p(cb.ptr), C.c_void_p(_dev_ptr(side)),
+                                     C.c_void_p(_dev_ptr(buf)), buf.numel(),
+                                     C.c_void_p(_dev_ptr(chunk_off)),
+                                     C.byref(total) if sync else None)
+        rc = run(payload)
+        if rc == L.HF_ERR_OVERFLOW and own_payload:
+            payload = torch.empty(int(L.lib().hf_payload_bound_words(n)), dtype=torch.int32,
+                                  device=dev)
+            rc = run(payload)
+        check(rc, "hf_encode")
         return EncodedStream(n=n, layout=lay, dtype=data_in.dtype, payload=payload,
                              chunk_off=chunk_off, side=side if lay == HF_LAYOUT_BF16_EXP else None,
                              codebook=cb, total_words=int(total.value) if sync else None)
@@ -519,16 +547,24 @@ class EntropyAwareHuffmanSystem(_Module):
         check(L.lib().hf_system_codebook_chunks_dev(h, C.c_void_p(freq.data_ptr()), nch, mode,
                                                     min_freq_threshold, C.c_void_p(cbs.data_ptr())),
               "hf_system_codebook_chunks_dev")
-        payload = torch.empty(max(4, n // 4 + nch * 192 + 64), dtype=torch.int32, device=dev)
+        payload = torch.empty(_payload_words_default(n, nch), dtype=torch.int32, device=dev)
         chunk_off = torch.empty(((nch + 1 + 3) // 4) * 4, dtype=torch.int32, device=dev)
         side = torch.empty(max(16, n), dtype=torch.uint8, device=dev) \
             if lay == HF_LAYOUT_BF16_EXP else None
         total = C.c_uint64(0)
-        check(L.lib().hf_encode_chunks(h, C.c_void_p(_dev_ptr(data_in)), n, lay,
-                                       C.c_void_p(cbs.data_ptr()), C.c_void_p(_dev_ptr(side)),
-                                       C.c_void_p(payload.data_ptr()), payload.numel(),
-                                       C.c_void_p(chunk_off.data_ptr()),
-                                       C.byref(total) if sync else None), "hf_encode_chunks")
+
+        def run(buf):
+            return L.lib().hf_encode_chunks(h, C.c_void_p(_dev_ptr(data_in)), n, lay,
+                                            C.c_void_p(cbs.data_ptr()), C.c_void_p(_dev_ptr(side)),
+                                            C.c_void_p(buf.data_ptr()), buf.numel(),
+                                            C.c_void_p(chunk_off.data_ptr()),
+                                            C.byref(total) if sync else None)
+        rc = run(payload)
+        if rc == L.HF_ERR_OVERFLOW:  # (min_freq_threshold can push a block past 8 bits per symbol)
+            payload = torch.empty(int(L.lib().hf_payload_bound_words(n)), dtype=torch.int32,
+                                  device=dev)
+            rc = run(payload)
+        check(rc, "hf_encode_chunks")
         return EncodedStream(n=n, layout=lay, dtype=data_in.dtype, payload=payload,
                              chunk_off=chunk_off, side=side, codebook=None,
                              total_words=int(total.value) if sync else None,
@@ -551,6 +587,7 @@ class EntropyAwareHuffmanSystem(_Module):
                      layout: Optional[int] = None) -> np.ndarray:
         """``encoded_out`` beats, one per symbol: columns code, length, compression_mode."""
         lay = layout_of(data_in) if layout is None else layout
+        data_in = data_in.contiguous()
         n = data_in.numel()
         beats = torch.empty(max(1, n), dtype=torch.int32, device=data_in.device)
         check(L.lib().hf_encode_pairs(self.ctx.handle, C.c_void_p(_dev_ptr(data_in)), n, lay,
@@ -588,7 +625,7 @@ class ParrallelHuffmanDecoder(_Module):  # spelling as in decoder/top_decoder.sc
                                        C.c_void_p(_dev_ptr(s.side)), s.n, s.layout,
                                        C.c_void_p(s.chunk_codebooks.data_ptr()),
                                        C.c_void_p(_dev_ptr(chunk_ids)), n_ids,
-                                       C.c_void_p(out.data_ptr()), 1 if check_stream else 0),
+                                       C.c_void_p(_dev_ptr(out)), 1 if check_stream else 0),
               "hf_decode_chunks")
         return out[:n_out]
 
@@ -622,6 +659,6 @@ class ParrallelHuffmanDecoder(_Module):  # spelling as in decoder/top_decoder.sc
         check(L.lib().hf_decode(self.ctx.handle, C.c_void_p(s.payload.data_ptr()),
                                 s.payload.numel(), C.c_void_p(s.chunk_off.data_ptr()),
                                 C.c_void_p(_dev_ptr(s.side)), s.n, s.layout,
-                                C.c_void_p(s.codebook.ptr), C.c_void_p(out.data_ptr()),
+                                C.c_void_p(s.codebook.ptr), C.c_void_p(_dev_ptr(out)),
                                 1 if check_stream else 0), "hf_decode")
         return out[:s.n]

@@ -70,10 +70,27 @@ int report_kernel_errors(hf_ctx* ctx) {
     return kerr_to_code(bits);
 }
 
-int use_device(hf_ctx* ctx) {
-    HF_HIP(hipSetDevice(ctx->device));
-    return HF_OK;
-}
+// Makes the context's device current for the duration of a call and puts the caller's device
+// back on the way out, so that a call on a context of another GPU does not move the thread's
+// later allocations and launches there.
+struct device_guard {
+    int prev = -1;
+    int enter(hf_ctx* ctx) {
+        int cur = -1;
+        HF_HIP(hipGetDevice(&cur));
+        if (cur != ctx->device) {
+            HF_HIP(hipSetDevice(ctx->device));
+            prev = cur;
+        }
+        return HF_OK;
+    }
+    ~device_guard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+#define HF_USE_DEVICE(ctx)  \
+    device_guard dev_guard_; \
+    if (int rc_ = dev_guard_.enter(ctx)) return rc_
 
 void tic(hf_ctx* ctx) {
     if (ctx->timing) {
@@ -131,6 +148,8 @@ int hf_ctx_create(hf_ctx** out, int device, void* stream) {
     memset(ctx, 0, sizeof(*ctx));
     ctx->device = device;
     ctx->stream = reinterpret_cast<hipStream_t>(stream);
+    int prev_dev = -1;
+    (void)hipGetDevice(&prev_dev);
     bool ok = hipSetDevice(device) == hipSuccess;
     hipDeviceProp_t prop;
     ok = ok && hipGetDeviceProperties(&prop, device) == hipSuccess;
@@ -144,19 +163,23 @@ int hf_ctx_create(hf_ctx** out, int device, void* stream) {
     ok = ok && hipMalloc(&ctx->d_ctl, 64) == hipSuccess;
     ok = ok && hipHostMalloc(&ctx->h_ctl, 64) == hipSuccess;
     ok = ok && hipMemset(ctx->d_ctl, 0, 64) == hipSuccess;  // ticket and the sticky error word
-    ok = ok && hipMalloc(&ctx->d_spill, hf_encode_spill_bytes(ctx->num_cu)) == hipSuccess;
+    // (the encoder's spill area, ~100 MB, is allocated by the first packed encode)
     ok = ok && hipEventCreate(&ctx->ev0) == hipSuccess;
     ok = ok && hipEventCreate(&ctx->ev1) == hipSuccess;
     if (!ok) {
         hf_ctx_destroy(ctx);
+        if (prev_dev >= 0 && prev_dev != device) (void)hipSetDevice(prev_dev);
         return HF_ERR_HIP;
     }
+    if (prev_dev >= 0 && prev_dev != device) (void)hipSetDevice(prev_dev);
     *out = ctx;
     return HF_OK;
 }
 
 int hf_ctx_destroy(hf_ctx* ctx) {
     if (!ctx) return HF_ERR_ARG;
+    int prev_dev = -1;
+    (void)hipGetDevice(&prev_dev);
     (void)hipSetDevice(ctx->device);
     if (ctx->stream || ctx->d_io) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_io) (void)hipFree(ctx->d_io);
@@ -172,13 +195,14 @@ int hf_ctx_destroy(hf_ctx* ctx) {
     if (ctx->d_cbscratch) (void)hipFree(ctx->d_cbscratch);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (prev_dev >= 0 && prev_dev != ctx->device) (void)hipSetDevice(prev_dev);
     delete ctx;
     return HF_OK;
 }
 
 int hf_sync(hf_ctx* ctx) {
     if (!ctx) return HF_ERR_ARG;
-    if (int rc = use_device(ctx)) return rc;
+    HF_USE_DEVICE(ctx);
     HF_HIP(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl, 64, hipMemcpyDeviceToHost, ctx->stream));
     HF_HIP(hipStreamSynchronize(ctx->stream));
     return report_kernel_errors(ctx);
@@ -186,7 +210,7 @@ int hf_sync(hf_ctx* ctx) {
 
 int hf_flush(hf_ctx* ctx) {
     if (!ctx) return HF_ERR_ARG;
-    if (int rc = use_device(ctx)) return rc;
+    HF_USE_DEVICE(ctx);
     HF_HIP(hipStreamSynchronize(ctx->stream));
     HF_HIP(hipMemsetAsync(ctx->d_freq, 0, 256 * sizeof(unsigned long long), ctx->stream));
     HF_HIP(hipMemsetAsync(ctx->d_ctl, 0, 64, ctx->stream));
@@ -208,7 +232,7 @@ int hf_set_timing(hf_ctx* ctx, int enabled) {
 int hf_last_kernel_ms(hf_ctx* ctx, float* ms) {
     if (!ctx || !ms) return HF_ERR_ARG;
     if (!ctx->timed) return HF_ERR_ARG;
-    if (int rc = use_device(ctx)) return rc;
+    HF_USE_DEVICE(ctx);
     HF_HIP(hipEventSynchronize(ctx->ev1));
     HF_HIP(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
     return HF_OK;
@@ -220,12 +244,13 @@ int hf_symbol_stat_dev(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
     if (!ctx || !d_freq256 || !layout_ok(layout) || (n && !d_data)) return HF_ERR_ARG;
     if (!aligned16(d_data) || !aligned16(d_freq256)) return HF_ERR_ALIGN;
     if (n > (1ull << 40)) return HF_ERR_RANGE;
-    if (int rc = use_device(ctx)) return rc;
+    HF_USE_DEVICE(ctx);
     tic(ctx);
     hf_launch_hist(d_data, n, norm_layout(layout), reinterpret_cast<unsigned long long*>(d_freq256),
                    ctx->num_cu, ctx->stream);
+    const hipError_t launch_err = hipGetLastError();  // before the event record can mask it
     toc(ctx);
-    HF_HIP(hipGetLastError());
+    HF_HIP(launch_err);
     return HF_OK;
 }
 
@@ -233,7 +258,7 @@ int hf_symbol_stat(hf_ctx* ctx, const void* d_data, uint64_t n, int layout, int 
                    uint64_t* h_freq) {
     if (!ctx || !h_freq || !layout_ok(layout) || (n && !d_data)) return HF_ERR_ARG;
     if (N < 2 || N > 256 || !is_pow2(N) || wt_width < 1 || wt_width > 64) return HF_ERR_ARG;
-    if (int rc = use_device(ctx)) return rc;
+    HF_USE_DEVICE(ctx);
     HF_HIP(hipMemsetAsync(ctx->d_freq, 0, 256 * sizeof(unsigned long long), ctx->stream));
     if (int rc = hf_symbol_stat_dev(ctx, d_data, n, layout,
                                     reinterpret_cast<uint64_t*>(ctx->d_freq)))
@@ -255,7 +280,7 @@ int hf_symbol_sort(hf_ctx* ctx, const uint64_t* h_freq, int N, uint64_t* h_sorte
     if (!ctx || !h_freq || !h_sorted || N < 2 || N > 256) return HF_ERR_ARG;
     for (int i = 0; i < N; ++i)
         if (h_freq[i] >> 56) return HF_ERR_RANGE;
-    if (int rc = use_device(ctx)) return rc;
+    HF_USE_DEVICE(ctx);
     memcpy(ctx->h_io->freq, h_freq, sizeof(uint64_t) * (size_t)N);
     if (int rc = run_stage(ctx, N, HF_OP_SORT, 0, 0)) return rc;
     memcpy(h_sorted, ctx->h_io->sorted, sizeof(uint64_t) * (size_t)N);
@@ -273,7 +298,7 @@ int hf_entropy(hf_ctx* ctx, const uint64_t* h_freq, int N, uint32_t* entropy_q16
         if (h_freq[i] >> 56) return HF_ERR_RANGE;
         tot += h_freq[i];
     }
-    if (int rc = use_device(ctx)) return rc;
+    HF_USE_DEVICE(ctx);
     memcpy(ctx->h_io->freq, h_freq, sizeof(uint64_t) * (size_t)N);
     if (int rc = run_stage(ctx, N, HF_OP_ENTROPY, 0, 0)) return rc;
     *entropy_q16 = ctx->h_io->entropy_q16;
@@ -322,7 +347,7 @@ int hf_tree_build(hf_ctx* ctx, const uint64_t* h_freqs, int N, int wt_width, uin
         tot += h_freqs[i];
         if (tot >= lim) return HF_ERR_RANGE;
     }
-    if (int rc = use_device(ctx)) return rc;
+    HF_USE_DEVICE(ctx);
     memcpy(ctx->h_io->freq, h_freqs, sizeof(uint64_t) * (size_t)N);
     if (int rc = run_stage(ctx, N, HF_OP_TREE, 0, 0)) return rc;
     const int M = 2 * N - 1;
@@ -339,7 +364,7 @@ int hf_tree_adjust(hf_ctx* ctx, const uint16_t* h_depths_in, int N, int max_dept
                    uint16_t* h_depths_out) {
     if (!ctx || !h_depths_in || !h_depths_out || N < 2 || N > 256) return HF_ERR_ARG;
     if (max_depth < 1 || max_depth > HF_MAX_CODE_LEN || (1 << max_depth) < N) return HF_ERR_ARG;
-    if (int rc = use_device(ctx)) return rc;
+    HF_USE_DEVICE(ctx);
     memcpy(ctx->h_io->depths, h_depths_in, sizeof(uint16_t) * (size_t)N);
     if (int rc = run_stage(ctx, N, HF_OP_ADJUST, max_depth, 0)) return rc;
     memcpy(h_depths_out, ctx->h_io->adj, sizeof(uint16_t) * (size_t)N);
@@ -363,7 +388,7 @@ int hf_codebook(hf_ctx* ctx, const uint64_t* h_freq, int N, const hf_entropy_con
         tot += h_freq[i];
         if (tot >> 56) return HF_ERR_RANGE;
     }
-    if (int rc = use_device(ctx)) return rc;
+    HF_USE_DEVICE(ctx);
     memcpy(ctx->h_io->freq, h_freq, sizeof(uint64_t) * (size_t)N);
     if (int rc = run_stage(ctx, N, HF_OP_CODEBOOK, lmax, thr)) return rc;
     memcpy(h_code, ctx->h_io->code, sizeof(uint16_t) * (size_t)N);
@@ -379,14 +404,15 @@ int hf_system_codebook_dev(hf_ctx* ctx, const uint64_t* d_freq256, int mode,
         mode != HF_MODE_BEST)
         return HF_ERR_ARG;
     if (!aligned16(d_freq256) || !aligned16(d_codebook)) return HF_ERR_ALIGN;
-    if (int rc = use_device(ctx)) return rc;
+    HF_USE_DEVICE(ctx);
     hf_cb_dev* cb = reinterpret_cast<hf_cb_dev*>(d_codebook);
     tic(ctx);
     hf_launch_system(reinterpret_cast<const unsigned long long*>(d_freq256), mode,
                      min_freq_threshold, cb, ctx->stream);
     hf_launch_tables(cb, ctx->stream);
+    const hipError_t launch_err = hipGetLastError();  // before the event record can mask it
     toc(ctx);
-    HF_HIP(hipGetLastError());
+    HF_HIP(launch_err);
     return HF_OK;
 }
 
@@ -398,7 +424,7 @@ int hf_codebook_upload(hf_ctx* ctx, const uint16_t* h_code, const uint8_t* h_len
     if (!aligned16(d_codebook)) return HF_ERR_ALIGN;
     for (int s = 0; s < 256; ++s)
         if (h_len[s] > HF_MAX_CODE_LEN) return HF_ERR_RANGE;
-    if (int rc = use_device(ctx)) return rc;
+    HF_USE_DEVICE(ctx);
     hf_cb_dev* h = ctx->h_cb;
     memset(h, 0, sizeof(hf_cb_dev));
     for (int s = 0; s < 256; ++s) {
@@ -420,7 +446,7 @@ int hf_codebook_upload(hf_ctx* ctx, const uint16_t* h_code, const uint8_t* h_len
 int hf_codebook_download(hf_ctx* ctx, const void* d_codebook, uint16_t* h_code, uint8_t* h_len,
                          int* mode, uint32_t* entropy_q16) {
     if (!ctx || !d_codebook) return HF_ERR_ARG;
-    if (int rc = use_device(ctx)) return rc;
+    HF_USE_DEVICE(ctx);
     HF_HIP(hipMemcpyAsync(ctx->h_cb, d_codebook, sizeof(hf_cb_dev), hipMemcpyDeviceToHost,
                           ctx->stream));
     HF_HIP(hipStreamSynchronize(ctx->stream));
@@ -437,7 +463,7 @@ int hf_encode_pairs(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
     if (!ctx || !d_codebook || !layout_ok(layout) || (n && (!d_data || !d_beats)))
         return HF_ERR_ARG;
     if (!aligned16(d_data) || !aligned16(d_beats) || !aligned16(d_codebook)) return HF_ERR_ALIGN;
-    if (int rc = use_device(ctx)) return rc;
+    HF_USE_DEVICE(ctx);
     hf_launch_pairs(d_data, n, norm_layout(layout), reinterpret_cast<const hf_cb_dev*>(d_codebook),
                     d_beats, ctx->stream);
     HF_HIP(hipGetLastError());
@@ -460,19 +486,24 @@ static int encode_common(hf_ctx* ctx, const void* d_data, uint64_t n, int layout
         !aligned16(d_chunk_off) || !aligned16(d_codebook))
         return HF_ERR_ALIGN;
     if (n > (1ull << 40)) return HF_ERR_RANGE;
-    if (int rc = use_device(ctx)) return rc;
+    HF_USE_DEVICE(ctx);
     const uint64_t nchunks = hf_num_chunks(n);
     if (nchunks > ctx->desc_cap) {
+        // grown geometrically (at least 64 Ki descriptors, 512 KiB), so that a context sees a
+        // handful of allocations over its life, whatever sizes it is asked for
         if (ctx->d_desc) {
             HF_HIP(hipStreamSynchronize(ctx->stream));
             HF_HIP(hipFree(ctx->d_desc));
             ctx->d_desc = nullptr;
-            ctx->desc_cap = 0;
         }
-        const size_t cap = (size_t)((nchunks + 1023) & ~1023ull);
+        size_t cap = ctx->desc_cap ? ctx->desc_cap * 2 : (size_t)65536;
+        ctx->desc_cap = 0;
+        while (cap < nchunks + 2) cap *= 2;
         HF_HIP(hipMalloc(&ctx->d_desc, cap * sizeof(unsigned long long)));
         ctx->desc_cap = cap;
     }
+    if (nchunks && !ctx->d_spill)
+        HF_HIP(hipMalloc(&ctx->d_spill, hf_encode_spill_bytes(ctx->num_cu)));
     HF_HIP(hipMemsetAsync(ctx->d_ctl, 0, sizeof(uint32_t), ctx->stream));  // the ticket only
     if (nchunks == 0) {
         HF_HIP(hipMemsetAsync(d_chunk_off, 0, sizeof(uint32_t), ctx->stream));
@@ -490,8 +521,9 @@ static int encode_common(hf_ctx* ctx, const void* d_data, uint64_t n, int layout
             hf_launch_encode(d_data, n, lay, reinterpret_cast<const hf_cb_dev*>(d_codebook), d_side,
                              d_payload, payload_cap_words, d_chunk_off, ctx->d_desc, ctx->d_ctl,
                              ctx->d_spill, ctx->d_ctl + 1, ctx->num_cu, ctx->stream);
+        const hipError_t launch_err = hipGetLastError();  // before the event record can mask it
         toc(ctx);
-        HF_HIP(hipGetLastError());
+        HF_HIP(launch_err);
     }
     if (h_total_words) {
         HF_HIP(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl, 64, hipMemcpyDeviceToHost, ctx->stream));
@@ -517,11 +549,12 @@ int hf_symbol_stat_chunks_dev(hf_ctx* ctx, const void* d_data, uint64_t n, int l
     if (!ctx || !layout_ok(layout) || (n && (!d_data || !d_freq_chunks))) return HF_ERR_ARG;
     if (!aligned16(d_data) || !aligned16(d_freq_chunks)) return HF_ERR_ALIGN;
     if (n > (1ull << 40)) return HF_ERR_RANGE;
-    if (int rc = use_device(ctx)) return rc;
+    HF_USE_DEVICE(ctx);
     tic(ctx);
     hf_launch_hist_chunks(d_data, n, norm_layout(layout), d_freq_chunks, ctx->stream);
+    const hipError_t launch_err = hipGetLastError();  // before the event record can mask it
     toc(ctx);
-    HF_HIP(hipGetLastError());
+    HF_HIP(launch_err);
     return HF_OK;
 }
 
@@ -533,15 +566,16 @@ int hf_system_codebook_chunks_dev(hf_ctx* ctx, const uint32_t* d_freq_chunks, ui
         return HF_ERR_ARG;
     if (!aligned16(d_freq_chunks) || !aligned16(d_chunk_codebooks)) return HF_ERR_ALIGN;
     if (nchunks > 0x7FFFFFFFull) return HF_ERR_RANGE;
-    if (int rc = use_device(ctx)) return rc;
+    HF_USE_DEVICE(ctx);
     if (nchunks && !ctx->d_cbscratch)
         HF_HIP(hipMalloc(&ctx->d_cbscratch, hf_chunk_cb_scratch_bytes()));
     tic(ctx);
     hf_launch_system_chunks(d_freq_chunks, nchunks, mode, min_freq_threshold,
                             reinterpret_cast<hf_chunk_cb*>(d_chunk_codebooks), ctx->d_cbscratch,
-                            ctx->stream);
+                            HF_CB_BATCH, ctx->stream);
+    const hipError_t launch_err = hipGetLastError();  // before the event record can mask it
     toc(ctx);
-    HF_HIP(hipGetLastError());
+    HF_HIP(launch_err);
     return HF_OK;
 }
 
@@ -569,15 +603,16 @@ static int decode_chunks_common(hf_ctx* ctx, const uint32_t* d_payload, uint64_t
         !aligned16(d_out_slots))
         return HF_ERR_ALIGN;
     if (n > (1ull << 40) || n_work > 0x7FFFFFFFull || n_slots > 0xFFFFFFFFull) return HF_ERR_RANGE;
-    if (int rc = use_device(ctx)) return rc;
+    HF_USE_DEVICE(ctx);
     if (n_work) {
         tic(ctx);
         hf_launch_decode_chunks(d_payload, payload_words, d_chunk_off, d_side, n, lay,
                                 reinterpret_cast<const hf_chunk_cb*>(d_chunk_codebooks),
                                 d_chunk_ids, d_out_slots, n_slots, n_ids, d_out, ctx->d_ctl + 1,
                                 ctx->num_cu, ctx->stream);
+        const hipError_t launch_err = hipGetLastError();  // before the event record can mask it
         toc(ctx);
-        HF_HIP(hipGetLastError());
+        HF_HIP(launch_err);
     }
     if (check) {
         HF_HIP(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl, 64, hipMemcpyDeviceToHost, ctx->stream));
@@ -609,7 +644,7 @@ int hf_decode_chunks_to(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload
 int hf_chunk_codebook_download(hf_ctx* ctx, const void* d_chunk_codebooks, uint64_t chunk,
                                uint16_t* h_code, uint8_t* h_len, int* mode, uint32_t* entropy_q16) {
     if (!ctx || !d_chunk_codebooks) return HF_ERR_ARG;
-    if (int rc = use_device(ctx)) return rc;
+    HF_USE_DEVICE(ctx);
     static_assert(sizeof(hf_chunk_cb) <= HF_CODEBOOK_DEV_BYTES, "staging buffer too small");
     const hf_chunk_cb* src = reinterpret_cast<const hf_chunk_cb*>(d_chunk_codebooks) + chunk;
     HF_HIP(hipMemcpyAsync(ctx->h_cb, src, sizeof(hf_chunk_cb), hipMemcpyDeviceToHost, ctx->stream));
@@ -637,14 +672,15 @@ int hf_decode(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
         !aligned16(d_chunk_off) || !aligned16(d_codebook))
         return HF_ERR_ALIGN;
     if (n > (1ull << 40)) return HF_ERR_RANGE;
-    if (int rc = use_device(ctx)) return rc;
+    HF_USE_DEVICE(ctx);
     if (n) {
         tic(ctx);
         hf_launch_decode(d_payload, payload_words, d_chunk_off, d_side, n, lay,
                          reinterpret_cast<const hf_cb_dev*>(d_codebook), d_out, ctx->d_ctl + 1,
                          ctx->num_cu, ctx->stream);
+        const hipError_t launch_err = hipGetLastError();  // before the event record can mask it
         toc(ctx);
-        HF_HIP(hipGetLastError());
+        HF_HIP(launch_err);
     }
     if (check) {
         HF_HIP(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl, 64, hipMemcpyDeviceToHost, ctx->stream));
@@ -717,7 +753,7 @@ int hf_container_pack(hf_ctx* ctx, hf_container_info* info, const void* d_codebo
     if (pl.off_side && pl.n && !d_side) return HF_ERR_ARG;
     if (!aligned16(d_blob) || !aligned16(d_codebook)) return HF_ERR_ALIGN;
     if (blob_cap_bytes < pl.total_bytes) return HF_ERR_OVERFLOW;
-    if (int rc = use_device(ctx)) return rc;
+    HF_USE_DEVICE(ctx);
     uint8_t* blob = reinterpret_cast<uint8_t*>(d_blob);
     hipStream_t s = ctx->stream;
     tic(ctx);
@@ -794,7 +830,7 @@ int hf_container_open(hf_ctx* ctx, const void* d_blob, uint64_t blob_bytes,
     if (!ctx || !d_blob || !info) return HF_ERR_ARG;
     if (!aligned16(d_blob)) return HF_ERR_ALIGN;
     if (blob_bytes < HF_CONTAINER_HEADER_BYTES) return HF_ERR_CORRUPT;
-    if (int rc = use_device(ctx)) return rc;
+    HF_USE_DEVICE(ctx);
     uint8_t* h = reinterpret_cast<uint8_t*>(ctx->h_io);
     HF_HIP(hipMemcpyAsync(h, d_blob, HF_CONTAINER_HEADER_BYTES, hipMemcpyDeviceToHost, ctx->stream));
     HF_HIP(hipStreamSynchronize(ctx->stream));
@@ -828,7 +864,7 @@ int hf_container_codebook(hf_ctx* ctx, const void* d_blob, const hf_container_in
                         &pl) ||
         pl.off_codebook != info->off_codebook)
         return HF_ERR_ARG;
-    if (int rc = use_device(ctx)) return rc;
+    HF_USE_DEVICE(ctx);
     const uint8_t* blob = reinterpret_cast<const uint8_t*>(d_blob);
     if (pl.codebook_kind == HF_CODEBOOK_STREAM) {
         if (info->mode > 1u) return HF_ERR_CORRUPT;

@@ -1055,16 +1055,17 @@ void hf_launch_system(const unsigned long long* d_freq256, int mode, unsigned lo
     hipLaunchKernelGGL(hf_k_system, dim3(1), dim3(64), 0, s, d_freq256, mode, thr, cb);
 }
 
-size_t hf_chunk_cb_scratch_bytes(void) { return (size_t)HF_CB_BATCH * (256 + 512 + 256 + 16); }
+static_assert(HF_CB_SCRATCH_PER_CHUNK == 256 + 512 + 256 + 16, "scratch layout (carve_scratch)");
+size_t hf_chunk_cb_scratch_bytes(void) { return (size_t)HF_CB_BATCH * HF_CB_SCRATCH_PER_CHUNK; }
 
 void hf_launch_system_chunks(const uint32_t* d_freq_chunks, uint64_t nchunks, int mode,
                              unsigned long long thr, hf_chunk_cb* cbs, void* d_scratch,
-                             hipStream_t s) {
-    if (nchunks == 0) return;
-    const ChunkScratch S = carve_scratch(d_scratch, HF_CB_BATCH);
-    // the scratch block holds HF_CB_BATCH codebooks; larger jobs go through it batch by batch
-    for (uint64_t c0 = 0; c0 < nchunks; c0 += HF_CB_BATCH) {
-        const uint32_t nb = (uint32_t)(nchunks - c0 < HF_CB_BATCH ? nchunks - c0 : HF_CB_BATCH);
+                             uint32_t batch, hipStream_t s) {
+    if (nchunks == 0 || batch == 0) return;
+    const ChunkScratch S = carve_scratch(d_scratch, batch);
+    // the scratch block holds `batch` codebooks; larger jobs go through it batch by batch
+    for (uint64_t c0 = 0; c0 < nchunks; c0 += batch) {
+        const uint32_t nb = (uint32_t)(nchunks - c0 < batch ? nchunks - c0 : batch);
         hipLaunchKernelGGL(hf_k_chunks_front, dim3(nb), dim3(64), 0, s, d_freq_chunks + c0 * 256, nb,
                            mode, S);
         hipLaunchKernelGGL(hf_k_chunks_merge, dim3((nb + 63) / 64), dim3(64), 0, s, nb, thr, S);

@@ -107,10 +107,12 @@ size_t hf_encode_spill_bytes(int num_cu);
 void hf_launch_hist_chunks(const void* d_data, uint64_t n, int layout, uint32_t* d_freq_chunks,
                            hipStream_t s);
 #define HF_CB_BATCH 65536u  // per-block codebooks built per pass through the scratch block
+#define HF_CB_SCRATCH_PER_CHUNK 1040u  // bytes of scratch per codebook in flight
 size_t hf_chunk_cb_scratch_bytes(void);
+// `batch` = codebooks the scratch block at d_scratch holds (HF_CB_SCRATCH_PER_CHUNK bytes each)
 void hf_launch_system_chunks(const uint32_t* d_freq_chunks, uint64_t nchunks, int mode,
                              unsigned long long thr, hf_chunk_cb* cbs, void* d_scratch,
-                             hipStream_t s);
+                             uint32_t batch, hipStream_t s);
 void hf_launch_encode_chunks(const void* d_data, uint64_t n, int layout, const hf_chunk_cb* cbs,
                              uint8_t* d_side, uint32_t* d_payload, uint64_t cap_words,
                              uint32_t* d_chunk_off, unsigned long long* d_desc,

@@ -103,14 +103,19 @@ __device__ __forceinline__ uint32_t decode_one(u64& win, int& room, const TAB& T
 // Copy payload words [gs, gs + W) into the wavefront's LDS window; gs is a multiple of 4 so
 // every access is a 16-byte one.  A well-formed chunk consumes no word at or past its end
 // `off1`, so the loads of the window's part behind the chunk's last 16-byte group are redirected
-// to that group (as are loads past the buffer, to its last 16 bytes): all loads are issued back
-// to back without branches, and the redirected ones fall on one line and move no further bytes.
+// to that group (as are loads past the buffer, to its last whole 16 bytes): all loads are issued
+// back to back without branches, and the redirected ones fall on one line and move no further
+// bytes.  A buffer whose size is not a multiple of four words ends in a group of one to three
+// words; when the chunk reaches into it (the stream's last chunk in a buffer of exactly the
+// stream's size) those words are fetched one by one behind a wave-uniform branch, so nothing is
+// ever read past the buffer.
 template <int W>
 __device__ __forceinline__ void stage_window_load(const uint32_t* __restrict__ payload,
                                                   const u64 payload_words, const u64 off1,
                                                   const u64 gs, const int lane,
                                                   uint4 (&v)[W / 256]) {
-    const u64 last_buf = (payload_words - 4) & ~3ull;  // the caller guarantees payload_words >= 4
+    const u64 whole = payload_words & ~3ull;  // words in whole 16-byte groups (>= 4: the caller
+    const u64 last_buf = whole - 4;           // guarantees payload_words >= 4)
     const u64 last_chunk = (off1 ? off1 - 1 : 0) & ~3ull;
     const u64 last = last_chunk < last_buf ? last_chunk : last_buf;
 #pragma unroll
@@ -119,6 +124,16 @@ __device__ __forceinline__ void stage_window_load(const uint32_t* __restrict__ p
         idx = idx < last ? idx : last;
         const hf_u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const hf_u32x4*>(payload + idx));
         v[k] = make_uint4(t.x, t.y, t.z, t.w);
+    }
+    if (__builtin_expect(payload_words != whole && last_chunk >= whole, 0)) {
+#pragma unroll
+        for (int k = 0; k < W / 256; ++k) {
+            if (gs + (u64)(k * 256 + lane * 4) == whole) {
+                v[k].x = payload[whole];
+                if (whole + 1 < payload_words) v[k].y = payload[whole + 1];
+                if (whole + 2 < payload_words) v[k].z = payload[whole + 2];
+            }
+        }
     }
 }
 template <int W>

@@ -20,6 +20,7 @@
 // of one tile overlaps the encoding of the next (see hf_k_encode).
 //
 // HBM traffic per bf16 element: 2 B read, 1 B side stream written, ~L/8 B payload written.
+#include <atomic>
 #include <type_traits>
 
 #include "hf_common.h"
@@ -614,16 +615,25 @@ static void launch_encode_impl(const void* d_data, uint64_t n, int layout, const
     const uint64_t cap = (uint64_t)num_cu * 2;  // two ~70 KiB workgroups fit one CU's LDS
     if (grid > cap) grid = cap;
     const size_t lds = sizeof(EncLds<PER_CHUNK>);
-    // more than 64 KiB of dynamic LDS has to be allowed per kernel and per device; the call is
-    // idempotent and cheap, so it is simply repeated before every launch
-    if (layout == HF_LAYOUT_BF16_EXP)
-        (void)hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&hf_k_encode<HF_LAYOUT_BF16_EXP, PER_CHUNK>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    else
-        (void)hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&hf_k_encode<HF_LAYOUT_U8, PER_CHUNK>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // more than 64 KiB of dynamic LDS has to be allowed per kernel and per device: done on a
+    // kernel's first launch on a device (one bit per device; repeating it is harmless, so two
+    // threads racing here only do it twice)
+    static std::atomic<unsigned long long> allowed[2];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    std::atomic<unsigned long long>& done = allowed[layout == HF_LAYOUT_BF16_EXP ? 1 : 0];
+    if (!(done.load(std::memory_order_relaxed) & bit)) {
+        const hipError_t e =
+            layout == HF_LAYOUT_BF16_EXP
+                ? hipFuncSetAttribute(
+                      reinterpret_cast<const void*>(&hf_k_encode<HF_LAYOUT_BF16_EXP, PER_CHUNK>),
+                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                : hipFuncSetAttribute(
+                      reinterpret_cast<const void*>(&hf_k_encode<HF_LAYOUT_U8, PER_CHUNK>),
+                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) done.fetch_or(bit, std::memory_order_relaxed);
+    }
     if (layout == HF_LAYOUT_BF16_EXP)
         hipLaunchKernelGGL((hf_k_encode<HF_LAYOUT_BF16_EXP, PER_CHUNK>), dim3((unsigned)grid),
                            dim3((kWaves + 1) * 64), lds, s, d_data, n, (uint32_t)nchunks, cb, d_side,

@@ -59,7 +59,9 @@ def allreduce_histogram(freq256: torch.Tensor, group=None) -> torch.Tensor:
     RCCL all-reduce over xGMI; with gloo (CPU tests) the same call on host tensors."""
     if freq256.dtype != torch.int64 or freq256.numel() != 256:
         raise ValueError("histogram must be int64[256]")
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    # (run whenever a process group exists, a group of one rank included: the collective is the
+    # same call at every world size, and a one-rank run then rehearses the very path N ranks take)
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(freq256, op=dist.ReduceOp.SUM, group=group)
     return freq256
 

@@ -631,3 +631,102 @@ def test_errors_of_enqueue_only_calls_are_kept_until_reported(hf):
     sys_.ctx.sync()                          # reported once
     assert np.array_equal(out.cpu().numpy(), sym)
     assert np.array_equal(dec.decode(s).cpu().numpy(), sym)
+
+
+@pytest.mark.parametrize("blocks", [False, True])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_decode_from_a_payload_buffer_of_exactly_the_stream_size(hf, orc, blocks, bf16):
+    # the decoder fetches the payload 16 bytes at a time; a buffer of exactly total_words words
+    # with total_words % 4 in {1, 2, 3} ends in a partial group, which must be read word by word
+    # (and nothing behind it: the words after the buffer's end are poisoned here)
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    dec = hf.ParrallelHuffmanDecoder(ctx=sys_.ctx)
+    seen = set()
+    for k in range(60):
+        n = 2 * 16384 + 900 + 37 * k
+        if bf16:
+            w = gaussian_bf16(n, seed=100 + k)
+            t = dev_bf16(w)
+        else:
+            t = dev_u8(skewed_symbols(n, 100 + k, "geometric"))
+        s = sys_.encode_blocks(t, mode=hf.HF_MODE_HUFFMAN) if blocks \
+            else sys_.encode(t, mode=hf.HF_MODE_HUFFMAN)
+        rem = s.total_words % 4
+        if rem == 0 or rem in seen:
+            continue
+        seen.add(rem)
+        buf = torch.full((s.total_words + 64,), -1, dtype=torch.int32, device=DEV)
+        buf[: s.total_words] = s.payload[: s.total_words]
+        s.payload = buf[: s.total_words]
+        assert s.payload.numel() % 4 == rem and s.payload.data_ptr() % 16 == 0
+        out = dec.decode(s)
+        assert torch.equal(out.view(torch.uint8), t.view(torch.uint8)), (rem, n)
+        if blocks:  # decode-on-read of the last full chunk and the first, from the same buffer
+            ids = torch.tensor([1, 0], dtype=torch.int32, device=DEV)
+            part = dec.decode_blocks(s, ids)
+            tv = t.view(torch.uint8).view(-1)
+            eb = 2 if bf16 else 1
+            exp = torch.cat([tv[16384 * eb:2 * 16384 * eb], tv[:16384 * eb]])
+            assert torch.equal(part.view(torch.uint8).view(-1), exp)
+        if seen == {1, 2, 3}:
+            break
+    assert seen == {1, 2, 3}
+
+
+def test_strided_views_are_made_contiguous_or_refused(hf, orc):
+    # the library walks memory from data_ptr(): a strided input is copied first, a strided output
+    # is refused (it could not be written through)
+    base = dev_u8(skewed_symbols(2 * 40000, 77, "geometric"))
+    view = base[::2]
+    assert not view.is_contiguous()
+    sym = view.cpu().numpy()
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    freq = hf.SymbolStat(ctx=sys_.ctx)(view)
+    assert np.array_equal(freq, orc.aw_symbol_stat(sym, 256, 32))
+    f2 = sys_.histogram(view).cpu().numpy().astype(np.uint64)
+    assert np.array_equal(f2, orc.aw_symbol_stat(sym, 256, 64))
+    cb = sys_.codebook(sys_.histogram(view), hf.HF_MODE_HUFFMAN)
+    s = sys_.encode_with(view, cb)
+    code, lens, _, _ = cb.download()
+    payload, _ = orc.rp_encode(sym, code, lens)
+    assert np.array_equal(s.payload[: payload.size].cpu().numpy().view(np.uint32), payload)
+    dec = hf.ParrallelHuffmanDecoder(ctx=sys_.ctx)
+    assert np.array_equal(dec.decode(s).cpu().numpy(), sym)
+    out = torch.empty(2 * sym.size, dtype=torch.uint8, device=DEV)[::2]
+    with pytest.raises(ValueError):
+        dec.decode(s, out=out)
+
+
+def test_default_payload_buffer_grows_for_a_foreign_codebook(hf, orc):
+    # a table built for one distribution used on the opposite one: more than 8 bits per symbol,
+    # which the default buffer does not hold; the host API answers the overflow report with the
+    # worst-case size instead of failing
+    f = np.sort(fib_counts())[::-1].copy()
+    code_r, len_r = orc.rp_codebook(f, 64, 0, 16)
+    mw = hf.MemWrapper()
+    for s_ in range(256):
+        mw.write(s_, int(code_r[s_]), int(len_r[s_]))
+    cb = mw.to_device()
+    sym = np.random.default_rng(10).integers(40, 256, 5 * 16384 + 9, dtype=np.uint8)
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    s = sys_.encode_with(dev_u8(sym), cb)
+    code, lens, _ = mw.bulk_read()
+    payload, off = orc.rp_encode(sym, code, lens)
+    assert s.total_words == payload.size > sym.size // 4 + 6 * 192 + 64
+    assert np.array_equal(s.payload[: payload.size].cpu().numpy().view(np.uint32), payload)
+    assert np.array_equal(hf.ParrallelHuffmanDecoder(ctx=sys_.ctx).decode(s).cpu().numpy(), sym)
+
+
+def test_a_call_leaves_the_callers_current_device_alone(hf):
+    # with one GPU there is nothing to move; the call must still leave device 0 current
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    sys_.encode(dev_u8(skewed_symbols(5000, 3, "geometric")), mode=hf.HF_MODE_HUFFMAN)
+    assert torch.cuda.current_device() == 0
+    if torch.cuda.device_count() > 1:
+        ctx1 = hf.Context(1)
+        assert torch.cuda.current_device() == 0
+        t1 = torch.randint(0, 256, (70000,), dtype=torch.uint8, device="cuda:1")
+        s1 = hf.EntropyAwareHuffmanSystem(ctx=ctx1).encode(t1, mode=hf.HF_MODE_HUFFMAN)
+        assert torch.cuda.current_device() == 0
+        assert torch.equal(hf.ParrallelHuffmanDecoder(ctx=ctx1).decode(s1), t1)
+        assert torch.cuda.current_device() == 0
