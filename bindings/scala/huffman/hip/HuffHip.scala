@@ -66,6 +66,10 @@ trait HuffHip extends Library {
                                 dFreqChunks: Pointer): Int              // u32[nchunks][256]
   def hf_system_codebook_chunks_dev(ctx: Pointer, dFreqChunks: Pointer, nchunks: Long, mode: Int,
                                     minFreq: Long, dChunkCodebooks: Pointer): Int
+  // the same records without any allocation on the call path (at most 4096 blocks per call; the
+  // batch scratch is a static device array): for graph capture and serving loops
+  def hf_system_codebook_chunks_static(ctx: Pointer, dFreqChunks: Pointer, nchunks: Long, mode: Int,
+                                       minFreq: Long, dChunkCodebooks: Pointer): Int
   def hf_encode_chunks(ctx: Pointer, dData: Pointer, n: Long, layout: Int, dChunkCodebooks: Pointer,
                        dSide: Pointer, dPayload: Pointer, payloadCapWords: Long, dChunkOff: Pointer,
                        hTotalWords: LongByReference): Int

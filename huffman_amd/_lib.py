@@ -23,6 +23,7 @@ HF_MAX_CODE_LEN = 16
 HF_MODE_BYPASS, HF_MODE_HUFFMAN, HF_MODE_AUTO, HF_MODE_BEST = 0, 1, 2, 3
 HF_CODEBOOK_DEV_BYTES = 20480
 HF_CHUNK_CODEBOOK_BYTES = 1552
+HF_STATIC_CB_MAX_CHUNKS = 4096
 HF_CONTAINER_VERSION = 1
 HF_CONTAINER_HEADER_BYTES = 128
 HF_CONTAINER_CHUNK_CODEBOOK_BYTES = 296
@@ -93,6 +94,7 @@ SIGNATURES = {
     "hf_decode": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, C.c_uint64, C.c_int, _vp, _vp, C.c_int]),
     "hf_symbol_stat_chunks_dev": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, _vp]),
     "hf_system_codebook_chunks_dev": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_uint64, _vp]),
+    "hf_system_codebook_chunks_static": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_uint64, _vp]),
     "hf_encode_chunks": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, _vp, _vp, _vp, C.c_uint64, _vp,
                                    _u64p]),
     "hf_decode_chunks": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, C.c_uint64, C.c_int, _vp, _vp,

@@ -23,11 +23,18 @@ struct hf_ctx {
     uint32_t* h_ctl;    // pinned, 16 words
     uint32_t* d_spill;
     void* d_cbscratch;  // per-block codebook batch scratch, allocated on first use
+    void* d_static_cbscratch;  // this device's copy of `scratch` below (never freed)
     hipEvent_t ev0, ev1;
     int timing;
     int timed;
     int last_hip;
 };
+
+// Scratch block of hf_system_codebook_chunks_static, the entry point that allocates nothing: room
+// for HF_STATIC_CB_MAX_CHUNKS per-block codebooks in flight between the three codebook kernels.
+// Every GPU the library runs on holds its own copy until the process ends; host code never uses
+// the array's name as an address, only the pointer hipGetSymbolAddress returned for the device.
+static __device__ __align__(256) unsigned char scratch[HF_STATIC_CB_MAX_CHUNKS * 1040u];
 
 namespace {
 
@@ -166,6 +173,9 @@ int hf_ctx_create(hf_ctx** out, int device, void* stream) {
     // (the encoder's spill area, ~100 MB, is allocated by the first packed encode)
     ok = ok && hipEventCreate(&ctx->ev0) == hipSuccess;
     ok = ok && hipEventCreate(&ctx->ev1) == hipSuccess;
+    // this device's address of the static scratch block (the device is current here)
+    ok = ok && hipGetSymbolAddress(&ctx->d_static_cbscratch, HIP_SYMBOL(scratch)) == hipSuccess &&
+         ctx->d_static_cbscratch != nullptr;
     if (!ok) {
         hf_ctx_destroy(ctx);
         if (prev_dev >= 0 && prev_dev != device) (void)hipSetDevice(prev_dev);
@@ -574,6 +584,32 @@ int hf_system_codebook_chunks_dev(hf_ctx* ctx, const uint32_t* d_freq_chunks, ui
                             reinterpret_cast<hf_chunk_cb*>(d_chunk_codebooks), ctx->d_cbscratch,
                             HF_CB_BATCH, ctx->stream);
     const hipError_t launch_err = hipGetLastError();  // before the event record can mask it
+    toc(ctx);
+    HF_HIP(launch_err);
+    return HF_OK;
+}
+
+// The same kernels with the batch scratch in the static device array: nothing is allocated or
+// freed on this path (hf_ctx_create fetched the array's address for the context's device).  The
+// kernels overwrite every scratch word they later read, so nothing has to be cleared between
+// calls; two calls in flight on one GPU at the same time (two contexts, two streams) would share
+// the block and race.
+int hf_system_codebook_chunks_static(hf_ctx* ctx, const uint32_t* d_freq_chunks, uint64_t nchunks,
+                                     int mode, uint64_t min_freq_threshold,
+                                     void* d_chunk_codebooks) {
+    if (!ctx || (nchunks && (!d_freq_chunks || !d_chunk_codebooks))) return HF_ERR_ARG;
+    if (mode != HF_MODE_BYPASS && mode != HF_MODE_HUFFMAN && mode != HF_MODE_AUTO &&
+        mode != HF_MODE_BEST)
+        return HF_ERR_ARG;
+    if (!aligned16(d_freq_chunks) || !aligned16(d_chunk_codebooks)) return HF_ERR_ALIGN;
+    if (nchunks > HF_STATIC_CB_MAX_CHUNKS) return HF_ERR_RANGE;  // more than the block holds
+    if (!ctx->d_static_cbscratch) return HF_ERR_HIP;
+    HF_USE_DEVICE(ctx);
+    tic(ctx);
+    hf_launch_system_chunks(d_freq_chunks, nchunks, mode, min_freq_threshold,
+                            reinterpret_cast<hf_chunk_cb*>(d_chunk_codebooks),
+                            ctx->d_static_cbscratch, HF_STATIC_CB_MAX_CHUNKS, ctx->stream);
+    const hipError_t launch_err = hipGetLastError();
     toc(ctx);
     HF_HIP(launch_err);
     return HF_OK;

@@ -211,6 +211,18 @@ int hf_symbol_stat_chunks_dev(hf_ctx* ctx, const void* d_data, uint64_t n, int l
  * per chunk; d_chunk_codebooks = nchunks records of HF_CHUNK_CODEBOOK_BYTES. */
 int hf_system_codebook_chunks_dev(hf_ctx* ctx, const uint32_t* d_freq_chunks, uint64_t nchunks,
                                   int mode, uint64_t min_freq_threshold, void* d_chunk_codebooks);
+/* hf_system_codebook_chunks_dev for callers that cannot allocate: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.
+ * The scratch the three codebook kernels pass a batch through sits in a static device array of
+ * HF_STATIC_CB_MAX_CHUNKS x 1040 bytes (4.06 MiB, held by every GPU the library runs on until the
+ * process ends) whose address hf_ctx_create looked up for the context's device, so the call
+ * allocates and frees nothing; same arguments, same records, bit for bit.  nchunks above
+ * HF_STATIC_CB_MAX_CHUNKS is refused with HF_ERR_RANGE.  All calls on one GPU share the block:
+ * two of them in flight at the same time (different contexts or streams) race. */
+#define HF_STATIC_CB_MAX_CHUNKS 4096u
+int hf_system_codebook_chunks_static(hf_ctx* ctx, const uint32_t* d_freq_chunks, uint64_t nchunks,
+                                     int mode, uint64_t min_freq_threshold,
+                                     void* d_chunk_codebooks);
 /* as hf_encode, chunk c coded with record c */
 int hf_encode_chunks(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
                      const void* d_chunk_codebooks, uint8_t* d_side, uint32_t* d_payload,
