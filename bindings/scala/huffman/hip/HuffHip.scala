@@ -1,5 +1,8 @@
-// JNA binding of libhuffhip.so (include/huffhip.h) with software twins of the reference's Chisel
-// modules: same class names, same constructor parameters, functions instead of ports.
+// JNA binding of libhuffhip.so (include/huffhip.h) with software twins of the reference's ten live
+// Chisel modules (SymbolStat, SymbolSort, ShannonEntropy, AdaptiveThreshold, HuffmanTreeBuilder,
+// tree_adjust, EntropyAwareTreeBuilder, MemWrapper, TreeQualityAnalyzer, EntropyAwareHuffmanSystem)
+// and of the decoder it only names (ParrallelHuffmanDecoder): same class names, same constructor
+// parameters, functions instead of ports.
 //
 // SOURCE ONLY: the image this library is built in has no JVM, sbt or JNA jar, so this file has
 // never been compiled.  It needs net.java.dev.jna:jna (5.x) on the class path and
@@ -132,6 +135,88 @@ class SymbolSort(val depth: Int, val wtWidth: Int)(implicit ctx: Pointer) {
     val sorted = new Array[Long](depth); val rank2sym = new Array[Short](depth)
     val rc = HuffHip.lib.hf_symbol_sort(ctx, freq, depth, sorted, rank2sym)
     require(rc == 0, s"hf_symbol_sort: $rc"); (sorted, rank2sym)
+  }
+}
+
+/** Software twin of ShannonEntropy (shannon_entropy.scala:11-118) with AdaptiveThreshold inside:
+  * `entropy_out` (Q16.16, the RTL's arithmetic) and `compression_mode`. */
+class ShannonEntropy(val depth: Int, val wtWidth: Int)(implicit ctx: Pointer) {
+  def apply(freq: Array[Long]): (Int, Int) = {
+    val e = new IntByReference(); val m = new IntByReference()
+    val rc = HuffHip.lib.hf_entropy(ctx, freq, depth, e, m)
+    require(rc == 0, s"hf_entropy: $rc"); (e.getValue, m.getValue)
+  }
+}
+
+/** Software twin of AdaptiveThreshold (adaptive_threshold.scala:11-87): the register set chosen
+  * for an entropy value, as (encoding_mode, compression_threshold Q16, tree_depth_limit,
+  * min_freq_threshold).  Host arithmetic, needs no context. */
+class AdaptiveThreshold(val depth: Int, val wtWidth: Int, val fracBits: Int = 16) {
+  def apply(entropyQ16: Int): (Int, Int, Int, Long) = {
+    val out = new com.sun.jna.Memory(24)
+    val rc = HuffHip.lib.hf_adaptive_threshold(entropyQ16, depth, wtWidth, out)
+    require(rc == 0, s"hf_adaptive_threshold: $rc")
+    (out.getInt(0), out.getInt(4), out.getInt(8), out.getLong(16))
+  }
+}
+
+/** What HuffmanTreeBuilder's ports hold when `done` rises (tree_build.scala:22-32); `depths` are
+  * true leaf depths (the RTL's port of that name is never driven). */
+case class HuffmanTree(root: Int, weights: Array[Long], lefts: Array[Short], rights: Array[Short],
+                       depths: Array[Short])
+
+/** Software twin of HuffmanTreeBuilder (tree_build.scala:17-140): merge priority (weight, index). */
+class HuffmanTreeBuilder(val numLeaves: Int, val wtWidth: Int)(implicit ctx: Pointer) {
+  def apply(freqs: Array[Long]): HuffmanTree = {
+    val m = 2 * numLeaves - 1
+    val w = new Array[Long](m); val l = new Array[Short](m); val r = new Array[Short](m)
+    val d = new Array[Short](numLeaves); val root = new ShortByReference()
+    val rc = HuffHip.lib.hf_tree_build(ctx, freqs, numLeaves, if (wtWidth <= 32) 32 else 64, w, l, r,
+                                       root, d)
+    require(rc == 0, s"hf_tree_build: $rc")
+    HuffmanTree(root.getValue & 0xFFFF, w, l, r, d)
+  }
+}
+
+/** Software twin of tree_adjust (tree_adjust.scala:6-127; lower-case name as there): the depth
+  * limiter with assign-by-rank. */
+class tree_adjust(val numLeaves: Int, val maxDepth: Int)(implicit ctx: Pointer) {
+  def apply(depthsIn: Array[Short]): Array[Short] = {
+    val out = new Array[Short](numLeaves)
+    val rc = HuffHip.lib.hf_tree_adjust(ctx, depthsIn, numLeaves, maxDepth, out)
+    require(rc == 0, s"hf_tree_adjust: $rc"); out
+  }
+}
+
+/** Software twin of MemWrapper (mem_wrapper.scala:6-87): write port, read port, bulk read and
+  * valid bits on the host; `toDevice` places the table where the encoder and decoder kernels
+  * read it (dCodebook: HF_CODEBOOK_DEV_BYTES of device memory). */
+class MemWrapper(val depth: Int = 256, val maxCodeLen: Int = 16, val addrWidth: Int = 8)
+                (implicit ctx: Pointer) {
+  private val code = new Array[Short](depth); private val len = new Array[Byte](depth)
+  private val valid = new Array[Boolean](depth)
+  def write(addr: Int, c: Int, l: Int): Unit = {
+    code(addr) = c.toShort; len(addr) = l.toByte; valid(addr) = true
+  }
+  def read(addr: Int): (Int, Int, Boolean) = (code(addr) & 0xFFFF, len(addr) & 0xFF, valid(addr))
+  def tableReady: Boolean = valid.forall(identity)
+  def bulkRead: (Array[Short], Array[Byte], Boolean) = (code.clone, len.clone, tableReady)
+  def flush(): Unit = java.util.Arrays.fill(valid, false)
+  def toDevice(dCodebook: Pointer, mode: Int = 1): Unit = {
+    require(depth == 256 && tableReady, "table_ready is low: write all 256 entries first")
+    val rc = HuffHip.lib.hf_codebook_upload(ctx, code, len, mode, dCodebook)
+    require(rc == 0, s"hf_codebook_upload: $rc")
+  }
+}
+
+/** Software twin of TreeQualityAnalyzer (tree_q_analyser.scala:10-47):
+  * (avg_length Q8, efficiency, compression_ratio) with the RTL's widths. */
+class TreeQualityAnalyzer(val depth: Int, val wtWidth: Int) {
+  def apply(freq: Array[Long], codeLength: Array[Byte]): (Int, Int, Int) = {
+    val a = new ShortByReference(); val e = new ShortByReference(); val r = new ShortByReference()
+    val rc = HuffHip.lib.hf_quality(Pointer.NULL, freq, codeLength, depth, wtWidth, a, e, r)
+    require(rc == 0, s"hf_quality: $rc")
+    (a.getValue & 0xFFFF, e.getValue & 0xFFFF, r.getValue & 0xFFFF)
   }
 }
 

@@ -128,6 +128,34 @@ __global__ __launch_bounds__(256) void k_wave_chunks(const uint8_t* __restrict__
     }
 }
 
+// The encoder's direction with the byte side written 16 bytes per lane: the bytes of two rounds are
+// paired up so that a wavefront's store covers 1 KiB instead of 512 bytes (what an exchange
+// between neighbouring lanes would make possible in the encoder).
+template <int NT>
+__global__ __launch_bounds__(256) void k_wave_chunks_enc16(const uint8_t* __restrict__ src,
+                                                           uint8_t* __restrict__ dst, size_t nchunks) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t nwaves = (size_t)gridDim.x * 4;
+    for (size_t c = wave; c < nchunks; c += nwaves) {
+        for (int r0 = 0; r0 < 32; r0 += 8) {
+            u32x4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const u32x4* q = (const u32x4*)(src + c * 32768 + (r0 + k) * 1024 + lane * 16);
+                v[k] = NT ? __builtin_nontemporal_load(q) : *q;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) {
+                u32x4* q = (u32x4*)(dst + c * 16384 + (r0 + k) * 512 + lane * 16);
+                const u32x4 o = {v[k].x ^ v[k].z, v[k].y ^ v[k].w, v[k + 1].x ^ v[k + 1].z,
+                                 v[k + 1].y ^ v[k + 1].w};
+                if (NT) __builtin_nontemporal_store(o, q); else *q = o;
+            }
+        }
+    }
+}
+
 template <typename F>
 static double time_ms(F launch, int reps) {
     hipEvent_t a, b;
@@ -197,6 +225,8 @@ int main(int argc, char** argv) {
             ROW("decoder-like (1 B in, 2 B out) nt", t, (k_wave_chunks<1, 1><<<g, 256>>>((const uint8_t*)src, (uint8_t*)dst, nchunks)));
             ROW("encoder-like (2 B in, 1 B out) plain", t, (k_wave_chunks<0, 0><<<g, 256>>>((const uint8_t*)src, (uint8_t*)dst, nchunks)));
             ROW("encoder-like (2 B in, 1 B out) nt", t, (k_wave_chunks<0, 1><<<g, 256>>>((const uint8_t*)src, (uint8_t*)dst, nchunks)));
+            ROW("encoder-like, 16-byte stores plain", t, (k_wave_chunks_enc16<0><<<g, 256>>>((const uint8_t*)src, (uint8_t*)dst, nchunks)));
+            ROW("encoder-like, 16-byte stores nt", t, (k_wave_chunks_enc16<1><<<g, 256>>>((const uint8_t*)src, (uint8_t*)dst, nchunks)));
         }
         {
             const unsigned g = (unsigned)(cu * 2);
