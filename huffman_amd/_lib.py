@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HUFFHIP_LIB") or os.path.join(_HERE, "lib", "libhuffhip.so")
 
 # ---- constants mirrored from include/huffhip.h ------------------------------------------------
-HF_ABI_VERSION = 1
+HF_ABI_VERSION = 2
 HF_OK = 0
 HF_ERR_ARG, HF_ERR_ALIGN, HF_ERR_RANGE, HF_ERR_HIP = -1, -2, -3, -4
 HF_ERR_OVERFLOW, HF_ERR_TIMEOUT, HF_ERR_CORRUPT, HF_ERR_NOMEM = -5, -6, -7, -8
@@ -21,7 +21,7 @@ HF_LAYOUT_U8, HF_LAYOUT_BF16_EXP, HF_LAYOUT_FP8 = 0, 1, 2
 HF_CHUNK_SYMS = 16384
 HF_MAX_CODE_LEN = 16
 HF_MODE_BYPASS, HF_MODE_HUFFMAN, HF_MODE_AUTO, HF_MODE_BEST = 0, 1, 2, 3
-HF_CODEBOOK_DEV_BYTES = 20480
+HF_CODEBOOK_DEV_BYTES = 36864
 HF_CHUNK_CODEBOOK_BYTES = 1552
 HF_STATIC_CB_MAX_CHUNKS = 4096
 HF_CONTAINER_VERSION = 1

@@ -418,8 +418,7 @@ int hf_system_codebook_dev(hf_ctx* ctx, const uint64_t* d_freq256, int mode,
     hf_cb_dev* cb = reinterpret_cast<hf_cb_dev*>(d_codebook);
     tic(ctx);
     hf_launch_system(reinterpret_cast<const unsigned long long*>(d_freq256), mode,
-                     min_freq_threshold, cb, ctx->stream);
-    hf_launch_tables(cb, ctx->stream);
+                     min_freq_threshold, cb, ctx->stream);  // codebook and decode tables
     const hipError_t launch_err = hipGetLastError();  // before the event record can mask it
     toc(ctx);
     HF_HIP(launch_err);

@@ -8,6 +8,8 @@
 //
 // Everything lives in one wavefront's registers and a ~11 KiB LDS block, and the kernels run one
 // wavefront per workgroup, so a barrier costs nothing; N (alphabet size) is a run-time value, 2 <= N <= 256.
+#include <stddef.h>
+
 #include "hf_common.h"
 
 namespace {
@@ -450,8 +452,34 @@ __global__ __launch_bounds__(64) void hf_k_stage(hf_stage_io* io, const int N, c
 // that matters for it: the leaf queue is the filtered counts in rank order read backwards (no
 // second sort), and no child link, leaf parent or leaf depth is written.  Returns the leaves per
 // level, level d in lane d, depths above lmax counted at lmax.
-__device__ __forceinline__ uint32_t system_tree_levels(CbLds& L, const u64* sorted, const u64 thr,
-                                                       const int lmax, const int lane) {
+//
+// Synchronisation inside one wavefront: its LDS operations complete in order, so a fence on both
+// sides of a wave barrier is all a store by one lane needs to be seen by the others.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ u64 uniform_u64(const u64 v) {
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    return ((u64)hi << 32) | (u64)lo;
+}
+
+// The same merge, whole runs of it at a time.  The two-queue merge takes its two nodes from the
+// leaf queue while the second of them is no heavier than the oldest internal node waiting (ties go
+// to the leaves), and that node does not change while only leaves are taken: a run of leaf-leaf
+// merges is as long as the number of leaf pairs whose second weight stays within that bound, which
+// one ballot tells, and the run's parents are made by as many lanes at once.  Likewise a run of
+// merges that take two internal nodes each lasts while the second of a pair is lighter than the
+// leaf at the head of its queue (and exists already).  Everything else -- a leaf with an internal
+// node -- is a single step.  The sequence of merges, hence every weight and parent link, is the
+// serial loop's; a histogram with many equal or zero counts needs a few dozen steps instead of
+// 255, a Fibonacci-like one as many as before.  One wavefront; uses only wave-level
+// synchronisation, so it may run while other wavefronts of the workgroup wait at a barrier.
+__device__ __forceinline__ uint32_t system_tree_levels_runs(CbLds& L, const u64* sorted,
+                                                            const u64 thr, const int lmax,
+                                                            const int lane) {
     constexpr int N = 256;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -459,32 +487,69 @@ __device__ __forceinline__ uint32_t system_tree_levels(CbLds& L, const u64* sort
         const u64 f = sorted[N - 1 - q];
         L.lq_w[q] = f < thr ? 0ull : f;  // sFilter, entropy_aware_tree_builder.scala:61-66
     }
-    __syncthreads();
-    if (lane == 0) {
-        int li = 0, ii = N;
-        u64 lw = L.lq_w[0], iw = 0;
-        for (int k = N; k < 2 * N - 1; ++k) {
-            u64 wt[2];
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const bool leaf = (li < N) && (ii >= k || lw <= iw);
-                if (leaf) {
-                    wt[p] = lw;
-                    ++li;
-                    lw = li < N ? L.lq_w[li] : 0;
-                } else {
-                    L.parent[ii] = (uint16_t)k;
-                    wt[p] = iw;
-                    ++ii;
-                    iw = ii < k ? L.w[ii] : 0;
-                }
-            }
-            const u64 ws = wt[0] + wt[1];
-            L.w[k] = ws;
-            if (ii == k) iw = ws;
+    wave_sync();
+    int li = 0, ii = N, k = N;  // next leaf, next internal node to take, next node to make
+    while (k < 2 * N - 1) {
+        const bool have_leaf = li < N;
+        const u64 lw = uniform_u64(L.lq_w[have_leaf ? li : N - 1]);
+        if (ii >= k) {
+            // no internal node waits (the very first merge): two leaves
+            const u64 ws = lw + L.lq_w[li + 1];
+            if (lane == 0) L.w[k] = ws;
+            li += 2;
+            ++k;
+            wave_sync();
+            continue;
         }
+        const u64 H = uniform_u64(L.w[ii]);
+        {   // leaf-leaf run: pair j takes leaves li + 2j and li + 2j + 1
+            const int idx = li + 2 * lane + 1;
+            const bool ok = idx < N && L.lq_w[idx < N ? idx : N - 1] <= H;
+            const u64 m = __ballot(ok);
+            const int t = m == ~0ull ? 64 : (int)__builtin_ctzll(~m);
+            if (t > 0) {
+                if (lane < t) L.w[k + lane] = L.lq_w[idx - 1] + L.lq_w[idx];
+                li += 2 * t;
+                k += t;
+                wave_sync();
+                continue;
+            }
+        }
+        if (have_leaf && lw <= H) {
+            // a leaf, then the internal node (the next leaf is heavier than it, or there is none)
+            if (lane == 0) {
+                L.parent[ii] = (uint16_t)k;
+                L.w[k] = lw + H;
+            }
+            ++li, ++ii, ++k;
+            wave_sync();
+            continue;
+        }
+        {   // internal-internal run over the nodes that exist now: pair j takes ii + 2j, ii + 2j + 1
+            const int idx = ii + 2 * lane + 1;
+            const bool ok = idx < k && (!have_leaf || L.w[idx < k ? idx : ii] < lw);
+            const u64 m = __ballot(ok);
+            const int t = m == ~0ull ? 64 : (int)__builtin_ctzll(~m);
+            if (t > 0) {
+                if (lane < t) {
+                    L.w[k + lane] = L.w[idx - 1] + L.w[idx];
+                    L.parent[idx - 1] = (uint16_t)(k + lane);
+                    L.parent[idx] = (uint16_t)(k + lane);
+                }
+                ii += 2 * t;
+                k += t;
+                wave_sync();
+                continue;
+            }
+        }
+        // the internal node, then a leaf (no second internal node lighter than it)
+        if (lane == 0) {
+            L.parent[ii] = (uint16_t)k;
+            L.w[k] = H + lw;
+        }
+        ++ii, ++li, ++k;
+        wave_sync();
     }
-    __syncthreads();
     uint32_t par[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) par[i] = lane + 64 * i < N - 2 ? L.parent[N + lane + 64 * i] : 0u;
@@ -509,74 +574,217 @@ __device__ __forceinline__ uint32_t system_tree_levels(CbLds& L, const u64* sort
     return h;
 }
 
+// ---- decode tables of a device codebook --------------------------------------------------------
+// Built in LDS by one workgroup of 256 threads from the encoder table and written out once.
+// First level: 2^12 entries indexed by the next 12 bits.  Codes longer than 12 bits share their
+// 12-bit prefix with at most 15 other codes; every distinct prefix gets a 16-entry second-level
+// table indexed by the following 4 bits, and its first-level entry carries that table's number
+// with length 0.  Works for any prefix-free code, canonical or not.  The multi-symbol table
+// follows from the first level: the entry for 12 bits that start with a code of len0 bits looks
+// the remaining 12 - len0 bits up again (left-aligned, zero-filled), and resolves a second symbol
+// when that entry's code fits into them.
+struct TabLds {
+    uint32_t enc[256];
+    uint16_t lut[HF_LUT_SIZE];
+    uint16_t sub[256 * 16];
+    uint16_t subidx[HF_LUT_SIZE];
+    uint32_t lut2[HF_LUT_SIZE];
+    uint32_t wide[128];  // symbols whose first-level span is more than 16 entries (length <= 7)
+    uint32_t cnt[4];     // second-level tables named by each wavefront's threads
+    uint32_t n_wide, max_len, hits;
+};
+static_assert(offsetof(hf_cb_dev, lut) % 16 == 0 && offsetof(hf_cb_dev, sub) % 16 == 0 &&
+              offsetof(hf_cb_dev, lut2) % 16 == 0, "tables are written 16 bytes at a time");
+
+// T.enc holds the encoder table (code | len << 16 by symbol); every thread of the 256 calls.
+__device__ void build_tables(TabLds& T, hf_cb_dev* cb, const int tid) {
+    const int lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) T.n_wide = T.max_len = T.hits = 0;
+    for (int i = tid; i < HF_LUT_SIZE; i += 256) {
+        T.lut[i] = 0;
+        T.sub[i] = 0;
+        T.subidx[i] = 0xFFFFu;
+    }
+    __syncthreads();
+    const uint32_t my = T.enc[tid];
+    const uint32_t my_len = my >> 16;
+    const uint32_t my_code = my & 0xFFFFu;
+    atomicMax(&T.max_len, my_len);
+    if (my_len >= 1 && my_len <= HF_LUT_BITS) {
+        const uint32_t span = 1u << (HF_LUT_BITS - my_len);
+        const uint32_t first = (my_code << (HF_LUT_BITS - my_len)) & (HF_LUT_SIZE - 1);
+        if (span <= 16) {
+            for (uint32_t k = 0; k < span; ++k) T.lut[first + k] = (uint16_t)((tid << 8) | my_len);
+        } else {
+            // (a prefix-free code has at most 2^7 codes of 7 bits or less)
+            const uint32_t slot = atomicAdd(&T.n_wide, 1u);
+            if (slot < 128) T.wide[slot] = (uint32_t)tid;
+        }
+    }
+    const bool is_long = my_len > HF_LUT_BITS && my_len <= HF_MAX_CODE_LEN;
+    const uint32_t my_prefix = is_long ? (my_code >> (my_len - HF_LUT_BITS)) & (HF_LUT_SIZE - 1) : 0;
+    if (is_long) T.subidx[my_prefix] = 0;  // mark (every writer stores the same value)
+    __syncthreads();
+    // the wide spans, all threads on one span at a time
+    const uint32_t n_wide = T.n_wide < 128u ? T.n_wide : 128u;
+    for (uint32_t w = 0; w < n_wide; ++w) {
+        const uint32_t sy = T.wide[w];
+        const uint32_t e = T.enc[sy];
+        const uint32_t len = e >> 16;
+        const uint32_t span = 1u << (HF_LUT_BITS - len);
+        const uint32_t first = ((e & 0xFFFFu) << (HF_LUT_BITS - len)) & (HF_LUT_SIZE - 1);
+        for (uint32_t k = tid; k < span; k += 256) T.lut[first + k] = (uint16_t)((sy << 8) | len);
+    }
+    // number the marked prefixes in ascending order: thread t owns entries 16t .. 16t+15
+    uint32_t c = 0;
+    for (int k = 0; k < 16; ++k) c += (T.subidx[tid * 16 + k] == 0);
+    uint32_t incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) T.cnt[wv] = incl;
+    __syncthreads();
+    uint32_t base = incl - c;
+    for (int w = 0; w < wv; ++w) base += T.cnt[w];
+    const uint32_t n_sub = T.cnt[0] + T.cnt[1] + T.cnt[2] + T.cnt[3];
+    for (int k = 0; k < 16; ++k) {
+        const int i = tid * 16 + k;
+        if (T.subidx[i] == 0) {
+            T.subidx[i] = (uint16_t)base;
+            T.lut[i] = (uint16_t)(base << 8);  // length 0 = escape to table `base`
+            ++base;
+        }
+    }
+    __syncthreads();
+    if (is_long) {
+        const uint32_t rem = my_len - HF_LUT_BITS;  // 1 .. 4 bits beyond the prefix
+        const uint32_t first = (my_code & ((1u << rem) - 1u)) << (4 - rem);
+        const uint32_t span = 1u << (4 - rem);
+        const uint32_t t = T.subidx[my_prefix];
+        for (uint32_t k = 0; k < span; ++k) T.sub[t * 16 + first + k] = (uint16_t)((tid << 8) | my_len);
+    }
+    __syncthreads();
+    uint32_t hits = 0;
+    for (int i = tid; i < HF_LUT_SIZE; i += 256) {
+        const uint32_t e0 = T.lut[i];
+        const uint32_t len0 = e0 & 0xFFu, sym0 = e0 >> 8;
+        uint32_t v = sym0 << 8;  // escape: the second-level table's number, lengths zero
+        if (len0 != 0) {
+            const uint32_t e1 = T.lut[((uint32_t)i << len0) & (HF_LUT_SIZE - 1)];
+            const uint32_t len1 = e1 & 0xFFu;
+            const bool two = len1 != 0 && len0 + len1 <= HF_LUT_BITS;
+            v = two ? (len0 + len1) | (sym0 << 8) | ((e1 >> 8) << 16) | ((len0 | 0x80u) << 24)
+                    : len0 | (sym0 << 8) | (len0 << 24);
+            hits += two;
+        }
+        T.lut2[i] = v;
+    }
+    hits = hf_wave_sum_u32(hits);
+    if (lane == 0) atomicAdd(&T.hits, hits);
+    __syncthreads();
+    for (int i = tid; i < HF_LUT_SIZE * 2 / 16; i += 256) {
+        reinterpret_cast<uint4*>(cb->lut)[i] = reinterpret_cast<const uint4*>(T.lut)[i];
+        reinterpret_cast<uint4*>(cb->sub)[i] = reinterpret_cast<const uint4*>(T.sub)[i];
+    }
+    for (int i = tid; i < HF_LUT_SIZE * 4 / 16; i += 256)
+        reinterpret_cast<uint4*>(cb->lut2)[i] = reinterpret_cast<const uint4*>(T.lut2)[i];
+    if (tid == 0) {
+        cb->n_sub = n_sub;
+        cb->max_len = T.max_len;
+        cb->pair_hits = T.hits;
+    }
+}
+
+// Tables for a codebook whose encoder table is already in place (hf_codebook_upload).
+__global__ __launch_bounds__(256) void hf_k_tables(hf_cb_dev* cb) {
+    __shared__ TabLds T;
+    T.enc[threadIdx.x] = cb->enc[threadIdx.x];
+    __syncthreads();
+    build_tables(T, cb, (int)threadIdx.x);
+}
+
 // ---- front half of EntropyAwareHuffmanSystem, device to device --------------------------------
 // stat counts (by raw symbol) -> sort -> entropy decision -> filter -> tree -> adjust(16) ->
 // canonical codes over ranks -> scatter through rank2sym (the RTL indexes the rank-ordered
-// table by raw symbol, top_encoder.scala:106 vs :155-157) -> encoder table.
-__global__ __launch_bounds__(64) void hf_k_system(const u64* __restrict__ freq256,
-                                                  const int mode_req, const u64 thr,
-                                                  hf_cb_dev* cb) {
+// table by raw symbol, top_encoder.scala:106 vs :155-157) -> encoder table -> decode tables.
+// One workgroup of four wavefronts: the first builds the codebook (a chain of wave-wide steps)
+// while the others wait at the barrier, then all four build the decode tables from the encoder
+// table left in LDS -- one launch, and the tables never make a trip through global memory.
+__global__ __launch_bounds__(256) void hf_k_system(const u64* __restrict__ freq256,
+                                                   const int mode_req, const u64 thr,
+                                                   hf_cb_dev* cb) {
     __shared__ CbLds L;
     __shared__ u64 sorted[256];
-    const int lane = hf_lane();
+    __shared__ TabLds T;
     const int N = 256;
-    stage_sort(freq256, N, sorted, L.rank2sym, lane);
-    const uint32_t ent = stage_entropy(freq256, N, lane);
-    const uint32_t emode = entropy_mode(ent);
-    // HF_MODE_BEST builds the Huffman tables first and keeps them only if they pay
-    uint32_t mode = mode_req == HF_MODE_BEST   ? (uint32_t)HF_MODE_HUFFMAN
-                    : mode_req == HF_MODE_AUTO ? emode
-                                               : (uint32_t)(mode_req & 1);
-    __syncthreads();
-    u64 bits = 0, cnt = 0;
-    if (mode == HF_MODE_HUFFMAN) {
-        uint32_t h = system_tree_levels(L, sorted, thr, HF_MAX_CODE_LEN, lane);
-        adjust_levels(h, HF_MAX_CODE_LEN, lane);
-        {
-            const uint32_t pidx[4] = {(uint32_t)lane, (uint32_t)lane + 64u, (uint32_t)lane + 128u,
-                                      (uint32_t)lane + 192u};
-            uint32_t dep[4], code[4];
-            assign_codes(h, HF_MAX_CODE_LEN, lane, pidx, dep, code);
+    if (threadIdx.x < 64) {  // (wave-uniform)
+        const int lane = hf_lane();
+        stage_sort(freq256, N, sorted, L.rank2sym, lane);
+        const uint32_t ent = stage_entropy(freq256, N, lane);
+        const uint32_t emode = entropy_mode(ent);
+        // HF_MODE_BEST builds the Huffman tables first and keeps them only if they pay
+        uint32_t mode = mode_req == HF_MODE_BEST   ? (uint32_t)HF_MODE_HUFFMAN
+                        : mode_req == HF_MODE_AUTO ? emode
+                                                   : (uint32_t)(mode_req & 1);
+        wave_sync();
+        u64 bits = 0, cnt = 0;
+        if (mode == HF_MODE_HUFFMAN) {
+            uint32_t h = system_tree_levels_runs(L, sorted, thr, HF_MAX_CODE_LEN, lane);
+            adjust_levels(h, HF_MAX_CODE_LEN, lane);
+            {
+                const uint32_t pidx[4] = {(uint32_t)lane, (uint32_t)lane + 64u,
+                                          (uint32_t)lane + 128u, (uint32_t)lane + 192u};
+                uint32_t dep[4], code[4];
+                assign_codes(h, HF_MAX_CODE_LEN, lane, pidx, dep, code);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                L.adj[pidx[i]] = (uint16_t)dep[i];
-                L.code[pidx[i]] = (uint16_t)code[i];
+                for (int i = 0; i < 4; ++i) {
+                    L.adj[pidx[i]] = (uint16_t)dep[i];
+                    L.code[pidx[i]] = (uint16_t)code[i];
+                }
+            }
+            wave_sync();
+            for (int p = lane; p < N; p += 64) {
+                const u64 f = sorted[p];
+                bits += f * (u64)L.adj[p];
+                cnt += f;
+            }
+            bits = hf_wave_sum_u64(bits);
+            cnt = hf_wave_sum_u64(cnt);
+            if (mode_req == HF_MODE_BEST && bits >= 8ull * cnt) mode = HF_MODE_BYPASS;
+        }
+        if (mode == HF_MODE_BYPASS) {
+            // bypass table, top_encoder.scala:131-137: code(i) = i, length = symWidth
+            for (int s = lane; s < 256; s += 64) {
+                T.enc[s] = (uint32_t)s | (8u << 16);
+                cb->enc[s] = (uint32_t)s | (8u << 16);
+                cb->code[s] = (uint16_t)s;
+                cb->len[s] = 8;
+            }
+            bits = 8, cnt = 1;
+        } else {
+            for (int p = lane; p < N; p += 64) {
+                const int s = L.rank2sym[p];
+                const uint32_t e = (uint32_t)L.code[p] | ((uint32_t)L.adj[p] << 16);
+                T.enc[s] = e;
+                cb->enc[s] = e;
+                cb->code[s] = L.code[p];
+                cb->len[s] = (uint8_t)L.adj[p];
             }
         }
-        __syncthreads();
-        for (int p = lane; p < N; p += 64) {
-            const u64 f = sorted[p];
-            bits += f * (u64)L.adj[p];
-            cnt += f;
-        }
-        bits = hf_wave_sum_u64(bits);
-        cnt = hf_wave_sum_u64(cnt);
-        if (mode_req == HF_MODE_BEST && bits >= 8ull * cnt) mode = HF_MODE_BYPASS;
-    }
-    if (mode == HF_MODE_BYPASS) {
-        // bypass table, top_encoder.scala:131-137: code(i) = i, length = symWidth
-        for (int s = lane; s < 256; s += 64) {
-            cb->enc[s] = (uint32_t)s | (8u << 16);
-            cb->code[s] = (uint16_t)s;
-            cb->len[s] = 8;
-        }
-        bits = 8, cnt = 1;
-    } else {
-        for (int p = lane; p < N; p += 64) {
-            const int s = L.rank2sym[p];
-            cb->enc[s] = (uint32_t)L.code[p] | ((uint32_t)L.adj[p] << 16);
-            cb->code[s] = L.code[p];
-            cb->len[s] = (uint8_t)L.adj[p];
+        if (lane == 0) {
+            cb->mode = mode;
+            cb->entropy_q16 = ent;
+            cb->entropy_mode = emode;
+            // expected payload of a full chunk: 16384 symbols x mean code length, in 32-bit
+            // words, plus the two look-ahead words each of the 64 lanes may leave behind
+            cb->chunk_words_hint =
+                cnt ? (uint32_t)(bits * (HF_CHUNK_SYMS / 32) / cnt) + 128u : 0u;
         }
     }
-    if (lane == 0) {
-        cb->mode = mode;
-        cb->entropy_q16 = ent;
-        cb->entropy_mode = emode;
-        // expected payload of a full chunk: 16384 symbols x mean code length, in 32-bit words,
-        // plus the two look-ahead words each of the 64 lanes may leave behind
-        cb->chunk_words_hint = cnt ? (uint32_t)(bits * (HF_CHUNK_SYMS / 32) / cnt) + 128u : 0u;
-    }
+    __syncthreads();
+    build_tables(T, cb, (int)threadIdx.x);
 }
 
 // ---- per-block codebooks ----------------------------------------------------------------------
@@ -913,79 +1121,6 @@ __global__ __launch_bounds__(64) void hf_k_system_chunks_rest(
     }
 }
 
-// Decode tables from enc[], assembled in LDS and written out once.  First level: 2^12 entries
-// indexed by the next 12 bits.  Codes longer than 12 bits share their 12-bit prefix with at most
-// 15 other codes; every distinct prefix gets a 16-entry second-level table indexed by the
-// following 4 bits, and its first-level entry carries that table's number with length 0.
-// Works for any prefix-free code, canonical or not.  One workgroup of 256 threads.
-__global__ __launch_bounds__(256) void hf_k_tables(hf_cb_dev* cb) {
-    __shared__ uint16_t lut[HF_LUT_SIZE];
-    __shared__ uint16_t sub[256 * 16];
-    __shared__ uint16_t subidx[HF_LUT_SIZE];
-    __shared__ uint32_t cnt[256];
-    __shared__ uint32_t max_len;
-    const int tid = threadIdx.x;
-    if (tid == 0) max_len = 0;
-    for (int i = tid; i < HF_LUT_SIZE; i += 256) {
-        lut[i] = 0;
-        sub[i] = 0;
-        subidx[i] = 0xFFFFu;
-    }
-    __syncthreads();
-    for (int s = 0; s < 256; ++s) {
-        const uint32_t e = cb->enc[s];
-        const uint32_t len = e >> 16;
-        const uint32_t code = e & 0xFFFFu;
-        if (len >= 1 && len <= HF_LUT_BITS) {
-            const uint32_t span = 1u << (HF_LUT_BITS - len);
-            const uint32_t first = (code << (HF_LUT_BITS - len)) & (HF_LUT_SIZE - 1);
-            for (uint32_t k = tid; k < span; k += 256) lut[first + k] = (uint16_t)((s << 8) | len);
-        }
-    }
-    const uint32_t my = cb->enc[tid];
-    const uint32_t my_len = my >> 16;
-    const uint32_t my_code = my & 0xFFFFu;
-    const bool is_long = my_len > HF_LUT_BITS && my_len <= HF_MAX_CODE_LEN;
-    const uint32_t my_prefix = is_long ? (my_code >> (my_len - HF_LUT_BITS)) & (HF_LUT_SIZE - 1) : 0;
-    atomicMax(&max_len, my_len);
-    if (is_long) subidx[my_prefix] = 0;  // mark (every writer stores the same value)
-    __syncthreads();
-    // number the marked prefixes in ascending order: thread t owns entries 16t .. 16t+15
-    uint32_t c = 0;
-    for (int k = 0; k < 16; ++k) c += (subidx[tid * 16 + k] == 0);
-    cnt[tid] = c;
-    __syncthreads();
-    uint32_t base = 0;
-    for (int t = 0; t < tid; ++t) base += cnt[t];
-    for (int k = 0; k < 16; ++k) {
-        const int i = tid * 16 + k;
-        if (subidx[i] == 0) {
-            subidx[i] = (uint16_t)base;
-            lut[i] = (uint16_t)(base << 8);  // length 0 = escape to table `base`
-            ++base;
-        }
-    }
-    __syncthreads();
-    if (is_long) {
-        const uint32_t rem = my_len - HF_LUT_BITS;  // 1 .. 4 bits beyond the prefix
-        const uint32_t first = (my_code & ((1u << rem) - 1u)) << (4 - rem);
-        const uint32_t span = 1u << (4 - rem);
-        const uint32_t t = subidx[my_prefix];
-        for (uint32_t k = 0; k < span; ++k) sub[t * 16 + first + k] = (uint16_t)((tid << 8) | my_len);
-    }
-    __syncthreads();
-    uint32_t n_sub = 0;
-    for (int t = 0; t < 256; ++t) n_sub += cnt[t];
-    for (int i = tid; i < HF_LUT_SIZE; i += 256) {
-        cb->lut[i] = lut[i];
-        cb->sub[i] = sub[i];
-    }
-    if (tid == 0) {
-        cb->n_sub = n_sub;
-        cb->max_len = max_len;
-    }
-}
-
 // encoder lookup mux, one beat per symbol (top_encoder.scala:148-162)
 template <int LAYOUT>
 __global__ __launch_bounds__(256) void hf_k_pairs(const void* __restrict__ data, const uint64_t n,
@@ -1052,7 +1187,7 @@ void hf_launch_stage(hf_stage_io* io, int N, int op, int lmax, unsigned long lon
 
 void hf_launch_system(const unsigned long long* d_freq256, int mode, unsigned long long thr,
                       hf_cb_dev* cb, hipStream_t s) {
-    hipLaunchKernelGGL(hf_k_system, dim3(1), dim3(64), 0, s, d_freq256, mode, thr, cb);
+    hipLaunchKernelGGL(hf_k_system, dim3(1), dim3(256), 0, s, d_freq256, mode, thr, cb);
 }
 
 static_assert(HF_CB_SCRATCH_PER_CHUNK == 256 + 512 + 256 + 16, "scratch layout (carve_scratch)");

@@ -29,8 +29,19 @@ struct hf_cb_dev {
     uint32_t max_len;
     uint32_t chunk_words_hint;   // payload words a full chunk is expected to take (symbol counts
                                  // x code lengths, schedule overhead included); 0 = unknown
-    uint32_t pad[2];
+    uint32_t pair_hits;          // entries of lut2 that resolve two symbols (of HF_LUT_SIZE)
+    uint32_t pad[1];
+    // Multi-symbol first level, by the next 12 bits.  Byte 0: bits consumed by what the entry
+    // resolves; byte 1: first symbol; byte 2: second symbol; byte 3: length of the first code,
+    // bit 7 set when the entry resolves two symbols (both codes lie inside the 12 bits).  An
+    // escape (first code longer than 12 bits) has bytes 0 and 3 zero and the second-level table's
+    // number in byte 1, as in `lut`.
+    uint32_t lut2[HF_LUT_SIZE];
 };
+// a stream is decoded two symbols per lookup when at least this many of the 4096 entries resolve
+// two symbols: with the code's own distribution (p = 2^-len) that is the probability that a pair
+// of symbols hits, and all 64 lanes of a wavefront must hit for the short path to be taken
+#define HF_PAIR_HITS_MIN 4053u   // 0.9895 ^ 64 = 0.51
 static_assert(sizeof(hf_cb_dev) <= HF_CODEBOOK_DEV_BYTES, "codebook struct outgrew its slot");
 
 // Per-chunk codebook record (HF_CHUNK_CODEBOOK_BYTES each): what the encoder needs by symbol

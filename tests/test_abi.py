@@ -49,7 +49,7 @@ def test_header_constants_match_binding():
 
 
 def test_host_only_entry_points(lib, orc):
-    assert lib.hf_abi_version() == 1
+    assert lib.hf_abi_version() == 2
     assert lib.hf_error_string(0) == b"ok" and b"aligned" in lib.hf_error_string(-2)
     for n in (0, 1, 16384, 16385, 10**9):
         assert lib.hf_num_chunks(n) == orc.num_chunks(n)
