@@ -10,10 +10,20 @@
 // than the window), so the symbol loop itself issues no payload loads; side bytes are
 // fetched two rounds ahead and outputs leave as one 16-byte store per lane and round.
 // Everything is touched once, so loads and stores are non-temporal.
-// A 12-bit first-level table in LDS resolves almost every symbol with one lookup; a longer
-// code takes one more lookup in a 16-entry second-level table named by the first.
+//
+// Lookup tables in LDS.  A stream whose codebook is short on average is decoded two symbols per
+// lookup: a 4096-entry table indexed by the next 12 bits resolves both symbols of a pair when
+// their codes fit into those bits together, which is what the pair-wise refill schedule of the
+// format asks for (a wavefront takes the short path when all 64 lanes hit; the codebook kernel
+// counts the entries that do and the decoder picks its path from that count).  Otherwise a
+// 12-bit first-level table resolves one symbol per lookup.  Either way a code longer than the
+// first level takes one more lookup in a 16-entry second-level table named by the first, and
+// that case is tested once per pair: an escape entry has length zero, so a lane that meets one
+// stands still and its second lookup returns the same entry.
 //
 // HBM traffic per bf16 element: ~L/8 B payload + 1 B side read, 2 B written.
+#include <stddef.h>
+
 #include "hf_common.h"
 
 namespace {
@@ -24,19 +34,117 @@ constexpr int kStageWords = 1024;   // payload window per wavefront, stream-wide
 constexpr int kStageWordsC = 512;   // payload window per wavefront, per-chunk tables (2 KiB)
 constexpr int kStageSlack = 64;    // never staged: room for the reads of a clamped position
 
-// Tables of a stream-wide codebook (any prefix-free code): shared by the workgroup.
+// a + (low byte of b), and "is the low byte of x zero" as a lane mask: one instruction each
+// (byte operand selection), where a mask and an add / a compare would take two
+__device__ __forceinline__ int add_byte0(const int a, const uint32_t b) {
+    int r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0"
+        : "=v"(r)
+        : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ u64 byte0_is_zero(const uint32_t x) {
+    u64 m;
+    asm("v_cmp_eq_u32_sdwa %0, %1, 0 src0_sel:BYTE_0 src1_sel:DWORD" : "=s"(m) : "v"(x));
+    return m;
+}
+
+// Table reads by LDS byte address.  Through a pointer the compiler adds the table's base to the
+// index in a vector instruction of its own, even when that base is a constant; with the address
+// formed here a constant base lands in the instruction's offset field and a wave-uniform one is
+// OR-ed in by the instruction that scales the index.
+typedef __attribute__((address_space(3))) const uint16_t hf_lds_u16;
+typedef __attribute__((address_space(3))) const uint32_t hf_lds_cu32;
+typedef __attribute__((address_space(3))) const uint8_t hf_lds_u8;
+__device__ __forceinline__ uint32_t lds_u16(const uint32_t byte_addr) {
+    return *reinterpret_cast<hf_lds_u16*>((uintptr_t)byte_addr);
+}
+__device__ __forceinline__ uint32_t lds_u32(const uint32_t byte_addr) {
+    return *reinterpret_cast<hf_lds_cu32*>((uintptr_t)byte_addr);
+}
+__device__ __forceinline__ uint32_t lds_u8(const uint32_t byte_addr) {
+    return *reinterpret_cast<hf_lds_u8*>((uintptr_t)byte_addr);
+}
+__device__ __forceinline__ uint32_t lds_address(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+// LDS layout of the stream-wide decoder, fixed so that table addresses are compile-time
+// constants: first level at 0 (the one-symbol table or the multi-symbol one, whichever the
+// codebook calls for), second level behind it, then the wavefronts' payload windows.
+constexpr uint32_t kLutAddr = 0;
+constexpr uint32_t kSubLds = 64;  // second-level tables kept in LDS (2 KiB); a codebook with more
+                                  // of them (up to 256) reads the others from global memory
+
+// a code longer than 12 bits: the first-level entry names a 16-entry table for bits 13..16.
+// Tables beyond the ones kept in LDS are read from the device codebook through the scalar cache,
+// one lane at a time: a vector load here, however rare, would make every wait for the side-byte
+// prefetch and the output stores of the symbol loop a wait for all of them.
+template <uint32_t SUB_ADDR>
+__device__ __forceinline__ uint32_t second_level(const uint16_t* __restrict__ sub_global,
+                                                 const uint32_t top, const uint32_t esc,
+                                                 uint32_t& len) {
+    const uint32_t idx = ((esc & 0xFFu) << 4) | ((top >> (32 - HF_LUT_BITS - 4)) & 0xFu);
+    uint32_t e2 = 0;
+    if (esc < kSubLds) e2 = lds_u16((idx << 1) + SUB_ADDR);
+    u64 far = __ballot(esc >= kSubLds);
+    while (far) {  // (the active lanes only)
+        const int l = (int)__builtin_ctzll(far);
+        far &= far - 1;
+        const uint32_t il = (uint32_t)__builtin_amdgcn_readlane((int)idx, l);
+        uint32_t w;
+        asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                     : "=s"(w)
+                     : "s"(sub_global), "s"((il >> 1) << 2)
+                     : "memory");
+        if (hf_lane() == l) e2 = (il & 1u) ? w >> 16 : w & 0xFFFFu;
+    }
+    len = e2 & 0xFFu;
+    return e2 >> 8;
+}
+
+// Tables of a stream-wide codebook (any prefix-free code), shared by the workgroup, one symbol
+// per lookup.  Entries: symbol << 8 | length, length 0 = escape with the second-level table's
+// number in the symbol field.
+template <uint32_t SUB_ADDR>
 struct DecTables {
     static constexpr int kBits = HF_LUT_BITS;
     static constexpr int kStage = kStageWords;
-    uint16_t lut[HF_LUT_SIZE];  // first level, by the next 12 bits
-    uint16_t sub[256 * 16];     // second level, 16 entries per escape, by the following 4 bits
+    static constexpr bool kPairs = false;
+    // the escape test once per pair: measured 2 % faster than once per symbol on a stream whose
+    // codes all fit the first level, no different on one where 0.4 % of the symbols do not
+    static constexpr bool kPairCheck = true;
+    const uint16_t* sub_global;  // the codebook's second-level tables in global memory
 
-    // a code longer than 12 bits: the first-level entry names a 16-entry table for bits 13..16
+    // first level, by the next 12 bits (2-byte entries)
+    __device__ __forceinline__ uint32_t lookup(const uint32_t top) const {
+        return lds_u16(((top >> (32 - kBits - 1)) & ((HF_LUT_SIZE - 1) * 2u)) + kLutAddr);
+    }
     __device__ __forceinline__ uint32_t long_code(const uint32_t top, const uint32_t esc,
                                                   uint32_t& len) const {
-        const uint32_t e2 = sub[(esc << 4) | ((top >> (32 - HF_LUT_BITS - 4)) & 0xFu)];
-        len = e2 & 0xFFu;
-        return e2 >> 8;
+        return second_level<SUB_ADDR>(sub_global, top, esc, len);
+    }
+};
+
+// The same codebook through the multi-symbol table (layout: hf_cb_dev::lut2).  `lookup` is its
+// one-symbol view, used where a pair does not resolve in one go.
+struct PairTables {
+    static constexpr int kBits = HF_LUT_BITS;
+    static constexpr int kStage = kStageWords;
+    static constexpr bool kPairs = true;
+    const uint16_t* sub_global;  // the codebook's second-level tables in global memory
+
+    // by the next 12 bits (4-byte entries)
+    __device__ __forceinline__ uint32_t lookup2(const uint32_t top) const {
+        return lds_u32(((top >> (32 - kBits - 2)) & ((HF_LUT_SIZE - 1) * 4u)) + kLutAddr);
+    }
+    __device__ __forceinline__ uint32_t lookup(const uint32_t top) const {
+        const uint32_t E = lookup2(top);
+        return (E & 0xFF00u) | ((E >> 24) & 0x7Fu);
+    }
+    __device__ __forceinline__ uint32_t long_code(const uint32_t top, const uint32_t esc,
+                                                  uint32_t& len) const {
+        return second_level<HF_LUT_SIZE * 4>(sub_global, top, esc, len);
     }
 };
 
@@ -48,13 +156,23 @@ struct DecTables {
 struct ChunkTables {
     static constexpr int kBits = 11;
     static constexpr int kStage = kStageWordsC;
+    static constexpr bool kPairs = false;
+    // the escape test per symbol: an 11-bit first level meets long codes often enough that the
+    // lookup a per-pair test wastes on them costs more than the test saves (0.64 against 0.66 ms
+    // per 65536 fp8 pages)
+    static constexpr bool kPairCheck = false;
     static constexpr int kLong = 16 - kBits;  // code lengths kBits+1 .. 16
-    const uint16_t* lut;     // LDS, 1 << kBits entries of this wavefront
+    uint32_t lut_addr;       // LDS address of this wavefront's 1 << kBits entries, a multiple of
+                             // the table's size (wave-uniform)
     const uint8_t* rank2sym; // LDS, 256 entries
     const uint16_t* tail;    // LDS, direct table over the code space of the long codes
     uint32_t tail_n;         // entries of `tail` in use; 0: that space is too large, use the blocks
     uint32_t start[kLong], end[kLong], off[kLong];  // per long length (wave-uniform)
 
+    __device__ __forceinline__ uint32_t lookup(const uint32_t top) const {
+        // index, scaled to bytes, with the table's address OR-ed in: two instructions
+        return lds_u16(((top >> (32 - kBits)) << 1) | lut_addr);
+    }
     __device__ __forceinline__ uint32_t long_code(const uint32_t top, const uint32_t,
                                                   uint32_t& len) const {
         const uint32_t v16 = top >> 16;
@@ -85,7 +203,7 @@ struct ChunkTables {
 template <class TAB>
 __device__ __forceinline__ uint32_t decode_one(u64& win, int& room, const TAB& T, uint32_t* err) {
     const uint32_t top = (uint32_t)(win >> 32);
-    uint32_t e = T.lut[top >> (32 - TAB::kBits)];
+    uint32_t e = T.lookup(top);
     if (__builtin_expect((e & 0xFFu) == 0, 0)) {
         uint32_t len;
         const uint32_t sym = T.long_code(top, e >> 8, len);
@@ -98,6 +216,76 @@ __device__ __forceinline__ uint32_t decode_one(u64& win, int& room, const TAB& T
     win <<= (e & 63u);  // lengths are <= 16; the 64-bit shift reads only these six bits
     room += (int)(e & 0xFFu);
     return e;
+}
+
+// Both symbols of a pair, one lookup each, the escape test once for the two: a lane whose first
+// lookup met an escape entry (length 0) has not moved, so its second lookup returns the same
+// entry -- "the second length is zero" covers both.  Entries e0, e1: symbol in byte 1.
+template <class TAB>
+__device__ __forceinline__ void decode_pair_single(u64& win, int& room, const TAB& T, uint32_t* err,
+                                                   uint32_t& e0, uint32_t& e1) {
+    e0 = T.lookup((uint32_t)(win >> 32));
+    win <<= (e0 & 63u);
+    e1 = T.lookup((uint32_t)(win >> 32));
+    if (__builtin_expect(byte0_is_zero(e1) != 0ull, 0)) {  // wave-uniform
+        if ((e1 & 0xFFu) == 0) {
+            if ((e0 & 0xFFu) == 0) {
+                // the first code is the long one: nothing was consumed yet
+                const uint32_t top = (uint32_t)(win >> 32);
+                uint32_t len;
+                const uint32_t sym = T.long_code(top, e0 >> 8, len);
+                if (len == 0) {
+                    atomicOr(err, HF_KERR_CORRUPT);
+                    len = 1;
+                }
+                e0 = (sym << 8) | len;
+                win <<= len;
+                e1 = T.lookup((uint32_t)(win >> 32));
+            }
+            if ((e1 & 0xFFu) == 0) {
+                const uint32_t top = (uint32_t)(win >> 32);
+                uint32_t len;
+                const uint32_t sym = T.long_code(top, e1 >> 8, len);
+                if (len == 0) {
+                    atomicOr(err, HF_KERR_CORRUPT);
+                    len = 1;
+                }
+                e1 = (sym << 8) | len;
+            }
+        }
+    }
+    win <<= (e1 & 63u);
+    room = add_byte0(room, e0 + e1);  // both lengths are <= 16: the byte sum does not carry
+}
+
+// A pair through the multi-symbol table.  Returns the symbols in bytes 1 and 2.  Every lane
+// consumes what its entry resolves -- both codes, the first code, or nothing (escape); the lanes
+// that are not through then finish the pair one symbol at a time, the others waiting.
+__device__ __forceinline__ uint32_t decode_pair_multi(u64& win, int& room, const PairTables& T,
+                                                      uint32_t* err) {
+    const uint32_t top = (uint32_t)(win >> 32);
+    const uint32_t E = T.lookup2(top);
+    win <<= (E & 63u);
+    room = add_byte0(room, E);
+    uint32_t P = E;
+    if (__builtin_expect(__ballot((int)E >= 0) != 0ull, 0)) {  // wave-uniform
+        if ((int)E >= 0) {
+            if ((E & 0xFFu) == 0) {  // the first code is longer than the table is wide
+                uint32_t len;
+                const uint32_t sym = T.long_code(top, (E >> 8) & 0xFFu, len);
+                if (len == 0) {  // no code matches: flag it and keep moving
+                    atomicOr(err, HF_KERR_CORRUPT);
+                    len = 1;
+                }
+                win <<= len;
+                room += (int)len;
+                P = sym << 8;
+            }
+            const uint32_t e1 = decode_one(win, room, T, err);
+            P = (P & 0xFF00u) | ((e1 & 0xFF00u) << 8);
+        }
+    }
+    return P;
 }
 
 // Copy payload words [gs, gs + W) into the wavefront's LDS window; gs is a multiple of 4 so
@@ -207,12 +395,20 @@ __device__ u64 decode_chunk_full(const uint32_t* __restrict__ payload, const u64
             lpos = lpos & 3u;
             stage_window<TAB::kStage>(payload, payload_words, off1, gs, stg, lane);
         }
-        uint32_t e[8];  // table entries: symbol in byte 1
+        // one-symbol tables: e[] holds the eight entries, symbol in byte 1; the multi-symbol
+        // table: P[] holds the four pairs, symbols in bytes 1 and 2
+        uint32_t e[8], P[4];
 #pragma unroll
         for (int jp = 0; jp < 4; ++jp) {
             refill<TAB::kStage>(room > 0, win, room, lpos, stg);
-            e[2 * jp] = decode_one(win, room, T, err);
-            e[2 * jp + 1] = decode_one(win, room, T, err);
+            if constexpr (TAB::kPairs)
+                P[jp] = decode_pair_multi(win, room, T, err);
+            else if constexpr (TAB::kPairCheck)
+                decode_pair_single(win, room, T, err, e[2 * jp], e[2 * jp + 1]);
+            else {
+                e[2 * jp] = decode_one(win, room, T, err);
+                e[2 * jp + 1] = decode_one(win, room, T, err);
+            }
         }
         if (LAYOUT == HF_LAYOUT_BF16_EXP) {
             // two bf16 per dword with packed operations (v_perm_b32; selector byte 0x0C reads
@@ -224,7 +420,11 @@ __device__ u64 decode_chunk_full(const uint32_t* __restrict__ payload, const u64
             for (int i = 0; i < 4; ++i) {
                 const uint32_t t = __builtin_amdgcn_perm(0u, i < 2 ? sd.x : sd.y,
                                                          (i & 1) ? 0x0C030C02u : 0x0C010C00u);
-                const uint32_t expo = __builtin_amdgcn_perm(e[2 * i + 1], e[2 * i], 0x0C050C01u);
+                uint32_t expo;
+                if constexpr (TAB::kPairs)
+                    expo = __builtin_amdgcn_perm(0u, P[i], 0x0C020C01u);
+                else
+                    expo = __builtin_amdgcn_perm(e[2 * i + 1], e[2 * i], 0x0C050C01u);
                 // the two three-operand forms are spelled out: the compiler splits them otherwise
                 uint32_t sm;
                 asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(sm) : "v"(t & 0x00800080u), "s"(255u), "v"(t));
@@ -236,6 +436,11 @@ __device__ u64 decode_chunk_full(const uint32_t* __restrict__ payload, const u64
                 reinterpret_cast<const hf_gmem_u32x2*>(su + pf * 512u + lane8));
             __builtin_nontemporal_store(hf_u32x4{o[0], o[1], o[2], o[3]},
                                         reinterpret_cast<hf_gmem_u32x4*>(ou + r * 1024u + lane16));
+        } else if constexpr (TAB::kPairs) {
+            const uint32_t lo = __builtin_amdgcn_perm(P[1], P[0], 0x06050201u);
+            const uint32_t hi = __builtin_amdgcn_perm(P[3], P[2], 0x06050201u);
+            __builtin_nontemporal_store(hf_u32x2{lo, hi},
+                                        reinterpret_cast<hf_gmem_u32x2*>(ou + r * 512u + lane8));
         } else {
             const uint32_t a = __builtin_amdgcn_perm(e[1], e[0], 0x0C0C0501u);
             const uint32_t b = __builtin_amdgcn_perm(e[3], e[2], 0x0C0C0501u);
@@ -298,43 +503,27 @@ __device__ u64 decode_chunk_tail(const uint32_t* __restrict__ payload, const u64
     return gs + lpos;
 }
 
-template <int LAYOUT>
-__global__ __launch_bounds__(kWaves * 64) void hf_k_decode(
+// LDS of the stream-wide decoder.  Byte streams may be decoded through the multi-symbol table
+// (4-byte entries), so their first level takes 16 KiB; 16-bit elements are bound by HBM either
+// way (the multi-symbol path measured 2 % slower there: twice the table to copy per workgroup,
+// nothing gained per symbol), so their kernel has the one-symbol table only.
+template <bool PAIRS_POSSIBLE>
+struct DecLds {
+    union {
+        uint16_t lut[HF_LUT_SIZE];
+        uint32_t lut2[PAIRS_POSSIBLE ? HF_LUT_SIZE : HF_LUT_SIZE / 2];
+    };
+    uint16_t sub[kSubLds * 16];
+    uint32_t stage[kWaves][kStageWords + kStageSlack];
+};
+
+// the chunks of one wavefront, through one kind of table
+template <int LAYOUT, class TAB>
+__device__ __forceinline__ void decode_chunks_of_wave(
     const uint32_t* __restrict__ payload, const uint64_t payload_words,
     const uint32_t* __restrict__ chunk_off, const uint8_t* __restrict__ side, const uint64_t n,
-    const uint32_t nchunks, const hf_cb_dev* __restrict__ cb, void* __restrict__ out,
-    uint32_t* err) {
-    __shared__ __attribute__((aligned(16))) DecTables T;
-    __shared__ __attribute__((aligned(16))) uint32_t stage[kWaves][kStageWords + kStageSlack];
-    const int lane = hf_lane();
-    const int wv = threadIdx.x >> 6;
-    uint32_t* stg = stage[wv];
-    const uint32_t wave = blockIdx.x * kWaves + wv;
-    const uint32_t nwaves = gridDim.x * kWaves;
-    // A workgroup lives for one chunk per wavefront, so what it waits for at its start counts.
-    // Everything it needs is requested in one go, without a branch in between: the chunk's
-    // offsets first (the window's addresses depend on them), the first-level table (one 16-byte
-    // piece per thread), the number of second-level tables, then the chunk's first payload window
-    // and the second-level tables in use; the LDS stores and the barrier follow.  Two memory
-    // round trips instead of five.
-    static_assert(kWaves * 64 * 16 == HF_LUT_SIZE * 2, "one 16-byte piece of the table per thread");
-    const uint32_t cw = wave < nchunks ? wave : nchunks - 1u;  // (nchunks >= 1)
-    const uint32_t o0 = __builtin_amdgcn_readfirstlane(chunk_off[cw]);
-    const uint32_t o1 = __builtin_amdgcn_readfirstlane(chunk_off[cw + 1]);
-    const uint4 t_lut = reinterpret_cast<const uint4*>(cb->lut)[threadIdx.x];
-    const uint32_t nsub = cb->n_sub < 256u ? cb->n_sub : 256u;
-    bool staged = wave < nchunks && o1 >= o0 && (uint64_t)o1 <= payload_words;
-    uint4 w[kStageWords / 256];
-    stage_window_load<kStageWords>(payload, payload_words, staged ? o1 : 0u,
-                                   staged ? (u64)o0 & ~3ull : 0ull, lane, w);
-    const bool has_sub = threadIdx.x < nsub * 2;  // 16 entries = two 16-byte pieces per table
-    const uint4 t_sub = reinterpret_cast<const uint4*>(cb->sub)[has_sub ? threadIdx.x : 0];
-    reinterpret_cast<uint4*>(T.lut)[threadIdx.x] = t_lut;
-    // (stored by every thread, so that the compiler keeps the load up there with the others:
-    // a second-level table no first-level entry names is never read, whatever it holds)
-    reinterpret_cast<uint4*>(T.sub)[threadIdx.x] = t_sub;
-    stage_window_store<kStageWords>(stg, lane, w);  // (likewise; unused when !staged)
-    __syncthreads();
+    const uint32_t nchunks, void* __restrict__ out, const TAB& T, uint32_t* __restrict__ stg,
+    uint32_t* err, const uint32_t wave, const uint32_t nwaves, bool staged, const int lane) {
     const size_t elem_bytes = LAYOUT == HF_LAYOUT_BF16_EXP ? 2 : 1;
     for (uint32_t c = wave; c < nchunks; c += nwaves) {
         const uint32_t off0 = __builtin_amdgcn_readfirstlane(chunk_off[c]);
@@ -361,6 +550,77 @@ __global__ __launch_bounds__(kWaves * 64) void hf_k_decode(
         staged = false;  // only the wavefront's first chunk was staged ahead
         // a well-formed chunk is consumed exactly
         if (end != off1 && lane == 0) atomicOr(err, HF_KERR_CORRUPT);
+    }
+}
+
+template <int LAYOUT>
+__global__ __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 6))) void
+hf_k_decode(const uint32_t* __restrict__ payload, const uint64_t payload_words,
+            const uint32_t* __restrict__ chunk_off, const uint8_t* __restrict__ side,
+            const uint64_t n, const uint32_t nchunks, const hf_cb_dev* __restrict__ cb,
+            void* __restrict__ out, uint32_t* err) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hf_dec_smem[];
+    constexpr bool kPairsPossible = LAYOUT != HF_LAYOUT_BF16_EXP;
+    typedef DecLds<kPairsPossible> Lds;
+    constexpr uint32_t kSubAddr = (uint32_t)offsetof(Lds, sub);
+    static_assert(offsetof(Lds, lut) == kLutAddr && (!kPairsPossible || kSubAddr == HF_LUT_SIZE * 4),
+                  "the tables' LDS addresses are compile-time constants");
+    Lds& S = *reinterpret_cast<Lds*>(hf_dec_smem);
+    const int lane = hf_lane();
+    // the table lookups take the block to start at LDS address 0 (it is the kernel's only LDS)
+    if (lds_address(hf_dec_smem) != 0u) {
+        if (threadIdx.x == 0) atomicOr(err, HF_KERR_CORRUPT);
+        return;
+    }
+    const int wv = threadIdx.x >> 6;
+    uint32_t* stg = S.stage[wv];
+    const uint32_t wave = blockIdx.x * kWaves + wv;
+    const uint32_t nwaves = gridDim.x * kWaves;
+    // A workgroup lives for one chunk per wavefront, so what it waits for at its start counts.
+    // Everything it needs is requested in one go, without a branch in between: the chunk's
+    // offsets first (the window's addresses depend on them), the first-level table (16-byte
+    // pieces), the number of second-level tables, then the chunk's first payload window and the
+    // second-level tables in use; the LDS stores and the barrier follow.  Two memory round trips
+    // instead of five.
+    constexpr int kThreads = kWaves * 64;
+    static_assert(kThreads * 16 >= HF_LUT_SIZE * 2 && kThreads * 32 >= HF_LUT_SIZE * 4 &&
+                  kThreads >= (int)kSubLds * 2, "one piece of the one-symbol table, two of the multi-symbol one, "
+                                   "one of the second level per thread");
+    const uint32_t cw = wave < nchunks ? wave : nchunks - 1u;  // (nchunks >= 1)
+    const uint32_t o0 = __builtin_amdgcn_readfirstlane(chunk_off[cw]);
+    const uint32_t o1 = __builtin_amdgcn_readfirstlane(chunk_off[cw + 1]);
+    const bool pairs = kPairsPossible && (uint32_t)__builtin_amdgcn_readfirstlane(
+                                             (int)cb->pair_hits) >= HF_PAIR_HITS_MIN;
+    // first level: 512 pieces of the one-symbol table, or 1024 of the multi-symbol one
+    const uint4* t_src = pairs ? reinterpret_cast<const uint4*>(cb->lut2)
+                               : reinterpret_cast<const uint4*>(cb->lut);
+    const uint32_t t_n = pairs ? HF_LUT_SIZE * 4 / 16 : HF_LUT_SIZE * 2 / 16;
+    const bool has_a = threadIdx.x < t_n, has_b = threadIdx.x + kThreads < t_n;
+    const uint4 t_a = t_src[has_a ? threadIdx.x : 0];
+    const uint4 t_b = t_src[has_b ? threadIdx.x + kThreads : 0];
+    const uint32_t nsub = cb->n_sub < kSubLds ? cb->n_sub : kSubLds;
+    bool staged = wave < nchunks && o1 >= o0 && (uint64_t)o1 <= payload_words;
+    uint4 w[kStageWords / 256];
+    stage_window_load<kStageWords>(payload, payload_words, staged ? o1 : 0u,
+                                   staged ? (u64)o0 & ~3ull : 0ull, lane, w);
+    const bool has_sub = threadIdx.x < nsub * 2;  // 16 entries = two 16-byte pieces per table
+    const uint4 t_sub = reinterpret_cast<const uint4*>(cb->sub)[has_sub ? threadIdx.x : 0];
+    if (has_a) reinterpret_cast<uint4*>(S.lut2)[threadIdx.x] = t_a;
+    if (has_b) reinterpret_cast<uint4*>(S.lut2)[threadIdx.x + kThreads] = t_b;
+    // (a second-level table no first-level entry names is never read, whatever it holds)
+    if (threadIdx.x < kSubLds * 2) reinterpret_cast<uint4*>(S.sub)[threadIdx.x] = t_sub;
+    stage_window_store<kStageWords>(stg, lane, w);  // (unused when !staged)
+    __syncthreads();
+    if (kPairsPossible && pairs) {
+        PairTables T;
+        T.sub_global = cb->sub;
+        decode_chunks_of_wave<LAYOUT>(payload, payload_words, chunk_off, side, n, nchunks, out, T,
+                                      stg, err, wave, nwaves, staged, lane);
+    } else {
+        DecTables<kSubAddr> T;
+        T.sub_global = cb->sub;
+        decode_chunks_of_wave<LAYOUT>(payload, payload_words, chunk_off, side, n, nchunks, out, T,
+                                      stg, err, wave, nwaves, staged, lane);
     }
 }
 
@@ -502,7 +762,7 @@ __device__ bool build_chunk_tables(const hf_chunk_cb* __restrict__ ccb, uint16_t
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    T.lut = lut;
+    T.lut_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(lut));
     T.rank2sym = r2s;
     T.tail = tail;
     return valid;
@@ -515,7 +775,9 @@ __global__ __launch_bounds__(kWavesC * 64) void hf_k_decode_chunks(
     const uint32_t nchunks, const hf_chunk_cb* __restrict__ cbs,
     const uint32_t* __restrict__ chunk_ids, const uint32_t* __restrict__ out_slots,
     const uint32_t n_slots, const uint32_t n_work, void* __restrict__ out, uint32_t* err) {
-    __shared__ __attribute__((aligned(16))) uint16_t lut_all[kWavesC][1 << ChunkTables::kBits];
+    // (aligned to a table's size: ChunkTables::lookup ORs the table's address into the index)
+    __shared__ __attribute__((aligned(4096))) uint16_t lut_all[kWavesC][1 << ChunkTables::kBits];
+    static_assert((2u << ChunkTables::kBits) == 4096u, "table size = its alignment");
     __shared__ __attribute__((aligned(16))) uint32_t stage[kWavesC][kStageWordsC + kStageSlack];
     __shared__ __attribute__((aligned(16))) uint8_t r2s_all[kWavesC][256];
     __shared__ __attribute__((aligned(16))) uint16_t tail_all[kWavesC][kTailEntries];
@@ -604,18 +866,20 @@ void hf_launch_decode(const uint32_t* d_payload, uint64_t payload_words,
                       hipStream_t s) {
     const uint64_t nchunks = (n + HF_CHUNK_SYMS - 1) / HF_CHUNK_SYMS;
     if (nchunks == 0) return;
-    // One chunk per wavefront, workgroups come and go (three 50 KiB workgroups fit one CU's LDS):
-    // measured 7-10 % faster on bf16 streams than a resident grid looping over the chunks, the
-    // same gain a kernel that only moves these bytes in this pattern shows; the price is one
-    // 16 KiB table copy out of L2 per eight chunks.
+    // One chunk per wavefront, workgroups come and go (three 52 KiB workgroups of eight wavefronts
+    // fit one CU's LDS): measured 7-10 % faster on bf16 streams than a resident grid looping over
+    // the chunks, the same gain a kernel that only moves these bytes in this pattern shows; the
+    // price is one table copy out of L2 per eight chunks.
     (void)num_cu;
     const uint64_t grid = (nchunks + kWaves - 1) / kWaves;
+    const size_t lds = layout == HF_LAYOUT_BF16_EXP ? sizeof(DecLds<false>) : sizeof(DecLds<true>);
+    static_assert(sizeof(DecLds<true>) <= 64 * 1024, "dynamic LDS within the default limit");
     if (layout == HF_LAYOUT_BF16_EXP)
         hipLaunchKernelGGL(hf_k_decode<HF_LAYOUT_BF16_EXP>, dim3((unsigned)grid),
-                           dim3(kWaves * 64), 0, s, d_payload, payload_words, d_chunk_off,
+                           dim3(kWaves * 64), lds, s, d_payload, payload_words, d_chunk_off,
                            d_side, n, (uint32_t)nchunks, cb, d_out, d_err);
     else
-        hipLaunchKernelGGL(hf_k_decode<HF_LAYOUT_U8>, dim3((unsigned)grid), dim3(kWaves * 64), 0, s,
-                           d_payload, payload_words, d_chunk_off, (const uint8_t*)nullptr, n,
+        hipLaunchKernelGGL(hf_k_decode<HF_LAYOUT_U8>, dim3((unsigned)grid), dim3(kWaves * 64), lds,
+                           s, d_payload, payload_words, d_chunk_off, (const uint8_t*)nullptr, n,
                            (uint32_t)nchunks, cb, d_out, d_err);
 }

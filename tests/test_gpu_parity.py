@@ -730,3 +730,52 @@ def test_a_call_leaves_the_callers_current_device_alone(hf):
         assert torch.cuda.current_device() == 0
         assert torch.equal(hf.ParrallelHuffmanDecoder(ctx=ctx1).decode(s1), t1)
         assert torch.cuda.current_device() == 0
+
+
+def test_codebook_with_200_second_level_tables(hf, orc):
+    # an uploaded prefix code in which 200 symbols have 16-bit codes with 200 different 12-bit
+    # prefixes: 200 second-level tables, of which the decoder keeps the first 64 in LDS and reads
+    # the others from the device codebook
+    code = np.zeros(256, np.uint16)
+    lens = np.zeros(256, np.uint8)
+    code[0], lens[0] = 0b0, 1
+    code[1], lens[1] = 0b10, 2
+    for i in range(200):
+        code[2 + i], lens[2 + i] = ((0xC00 + i) << 4) | (i & 0xF), 16
+    for j in range(54):
+        code[202 + j], lens[202 + j] = 0xC00 + 200 + j, 12
+    mw = hf.MemWrapper()
+    for s_ in range(256):
+        mw.write(s_, int(code[s_]), int(lens[s_]))
+    cb = mw.to_device()
+    rng = np.random.default_rng(77)
+    sym = rng.choice(256, 5 * 16384 + 1234, p=np.r_[0.3, 0.2, np.full(254, 0.5 / 254)]).astype(np.uint8)
+    sym[:256] = np.arange(256)
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    bound = int(hf.L.lib().hf_payload_bound_words(sym.size))
+    s = sys_.encode_with(dev_u8(sym), cb, payload=torch.empty(bound, dtype=torch.int32, device=DEV))
+    payload, off = orc.rp_encode(sym, code, lens)
+    assert s.total_words == payload.size
+    assert np.array_equal(s.payload[: payload.size].cpu().numpy().view(np.uint32), payload)
+    assert np.array_equal(hf.ParrallelHuffmanDecoder(ctx=sys_.ctx).decode(s).cpu().numpy(), sym)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_streams_that_mix_pair_hits_misses_and_long_codes(hf, orc, bf16):
+    # a short average code (decoded two symbols per lookup) with rare symbols sprinkled in, so that
+    # within one wavefront some lanes resolve a pair in one lookup, some need the second lookup and
+    # some meet a code longer than the first-level table; whole payload against the oracle
+    rng = np.random.default_rng(31)
+    n = 9 * 16384 + 777
+    sym = np.minimum(rng.geometric(0.55, n) - 1, 255).astype(np.uint8)
+    rare = rng.random(n) < 0.01
+    sym[rare] = rng.integers(20, 256, int(rare.sum()), dtype=np.uint8)
+    if bf16:
+        low = rng.integers(0, 128, n).astype(np.uint16)
+        w = (rng.integers(0, 2, n).astype(np.uint16) << 15) | (sym.astype(np.uint16) << 7) | low
+        s2, side = orc.symbolize(w, orc.LAYOUT_BF16_EXP)
+        s = system_roundtrip(hf, orc, dev_bf16(w), s2, mode=hf.HF_MODE_HUFFMAN, side=side)
+    else:
+        s = system_roundtrip(hf, orc, dev_u8(sym), sym, mode=hf.HF_MODE_HUFFMAN)
+    lens = s.codebook.download()[1]
+    assert lens.max() > 12 and float((np.bincount(sym, minlength=256) * lens).sum()) / n < 3.0
