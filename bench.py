@@ -24,6 +24,20 @@ if ROOT not in sys.path:
 LLAMA3_8B_PARAMS = 8_030_261_248
 SLAB = 256 * 1024 * 1024
 HBM_PEAK_GBPS = 8000.0
+METRIC = ("encode+decode GB/s (uncompressed bytes through histogram, codebook, encode and decode "
+          "per second), % HBM roofline, comp. ratio")
+
+
+def library_hash():
+    """First 16 hex digits of sha256(libhuffhip.so): ties a bench line and a counter summary to
+    the build they were taken from."""
+    import hashlib
+    from huffman_amd import _lib
+    h = hashlib.sha256()
+    with open(_lib.LIB_PATH, "rb") as f:
+        for block in iter(lambda: f.read(1 << 20), b""):
+            h.update(block)
+    return h.hexdigest()[:16]
 
 
 def make_weights(torch, n, device):
@@ -99,8 +113,10 @@ def cpu_baseline(torch, w_gpu, sample_elems):
     return res
 
 
-def pmc_traffic(n):
-    """HBM bytes per launch from the committed rocprofv3 counter passes of this same workload.
+def pmc_traffic(n, lib_hash):
+    """HBM bytes per launch from the committed rocprofv3 counter passes of this same workload,
+    taken with this very build of the library (the summary records the library's hash; one from
+    another build is not quoted, so that a kernel change cannot silently carry old traffic).
 
     The counters cannot be read from inside this process; tools/profile_bench.sh collects
     FETCH_SIZE and WRITE_SIZE in separate --pmc runs of this script and writes a summary under
@@ -116,7 +132,7 @@ def pmc_traffic(n):
                 d = json.load(f)
         except (OSError, ValueError):
             continue
-        if d.get("elements_per_gpu") != n:
+        if d.get("elements_per_gpu") != n or d.get("library_sha256_16") != lib_hash:
             continue
         out = {}
         for phase, kern in (("hist", "hf_k_hist"), ("encode", "hf_k_encode"),
@@ -161,7 +177,19 @@ def main():
                     help="bf16 elements per GPU (default: Llama-3-8B parameter count)")
     ap.add_argument("--cpu-sample", type=int, default=1536 * 1024 * 1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", type=int, default=2, choices=(1, 2, 3, 5),
+                    help="workload: 2 = the headline bf16 weight stream (default); 1 = one 4 KB "
+                         "block of uniform bytes; 3 = fp8 KV-cache pages with per-page codebooks; "
+                         "5 = the codebook kernels on degenerate count shapes (1, 3, 5: one GPU)")
+    ap.add_argument("--pages", type=int, default=1 << 18, help="config 3: 16 KiB pages")
     args = ap.parse_args()
+
+    if args.config != 2:
+        if args.gpus != 1:
+            raise SystemExit("configs 1, 3 and 5 are single-GPU workloads")
+        import bench_configs
+        return {1: bench_configs.config1, 3: bench_configs.config3,
+                5: bench_configs.config5}[args.config](args)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))
@@ -300,7 +328,8 @@ def main():
         "decode": n * (1.0 + lbar / 8.0 + 2.0) + 4.0 * nch,
     }
     roof = {}
-    pmc, pmc_src = pmc_traffic(n)
+    lib_hash = library_hash()
+    pmc, pmc_src = pmc_traffic(n, lib_hash)
     for p in ("hist", "encode", "decode"):
         ach = alg[p] / (ms[p] * 1e-3) / 1e9
         roof[p] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -310,8 +339,7 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "encode+decode GB/s (uncompressed bf16 bytes through histogram, codebook, "
-                      "encode and decode per second), % HBM roofline, comp. ratio",
+            "metric": METRIC,
             "value": raw_bytes * world * args.steps / elapsed / 1e9,
             "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -339,6 +367,7 @@ def main():
             "compression_mode": mode, "entropy_q16": ent,
             "tree_quality": quality,
             "roundtrip_bit_exact": ok,
+            "library_sha256_16": lib_hash,
             "roofline": dict(roof[dominant], kernel=dominant),
             "roofline_all": roof,
         }

@@ -1,0 +1,418 @@
+"""The single-GPU workloads of bench.py besides the headline one (`bench.py --config 1|3|5`).
+
+config 1  one 4 KB block of uniform random bytes (the only size the reference's RTL speaks about):
+          histogram -> codebook -> encode -> decode, latency per block and blocks per second
+config 3  fp8 E4M3 KV-cache pages (16 tokens x 1024 bytes), one codebook per page: per-page
+          histogram -> batched codebooks -> encode -> decode, plus decode-on-read of 4096 random
+          pages into a page pool
+config 5  the codebook kernels alone on the degenerate count shapes: microseconds per codebook
+          (one stream-wide codebook) and codebooks per second (batched per-block path)
+
+Each prints one JSON line of the same shape as the headline run, with `roofline` (or
+`"bound": "latency"` where a kernel's time is fixed by a serial chain, not by bytes moved) and
+`cpu_baseline` (the CPU oracle, a scalar C restatement, on a bounded sample).
+"""
+import ctypes as C
+import json
+import time
+
+import bench
+
+CH = 16384
+# Derived from the reference's state machines (not simulated, there is no simulator here):
+# SymbolStat n + 2, SymbolSort 2N + 3, ShannonEntropy N + 2, HuffmanTreeBuilder N + 2, tree_adjust
+# ~N, code generation 2, the lookup mux n cycles (symbol_stat.scala:34-38,
+# symbol_sort.scala:138-141, shannon_entropy.scala:67-97, tree_build.scala:111-125,
+# tree_adjust.scala:108-119, top_encoder.scala:148-162): about 2 n + 1300 cycles per block.
+RTL_CYCLES_4K = 2 * 4096 + 1300
+
+
+def _events(torch, n):
+    return [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+
+
+def _phase_ms(evs, names):
+    k = len(evs)
+    return {p: sum(e[i].elapsed_time(e[i + 1]) for e in evs) / k for i, p in enumerate(names)}
+
+
+def _roof(alg_bytes, ms, bound="hbm", **extra):
+    ach = alg_bytes / (ms * 1e-3) / 1e9
+    d = {"bound": bound, "achieved": ach, "peak": bench.HBM_PEAK_GBPS, "unit": "GB/s",
+         "frac": ach / bench.HBM_PEAK_GBPS, "traffic": None, "ms": ms,
+         "algorithmic_bytes": alg_bytes}
+    d.update(extra)
+    return d
+
+
+def config1(args):
+    """4096 symbols, uniform over 0..255, seed 1, Huffman forced."""
+    import numpy as np
+    import torch
+    from huffman_amd import api as hf
+    from oracle import oracle as orc
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    n = 4096
+    sym = np.random.default_rng(1).integers(0, 256, n, dtype=np.uint8)
+    t = torch.from_numpy(sym).to(dev)
+    ctx = hf.Context(0)
+    system = hf.EntropyAwareHuffmanSystem(ctx=ctx)
+    decoder = hf.ParrallelHuffmanDecoder(ctx=ctx)
+    stat = hf.SymbolStat(ctx=ctx)
+    freq = torch.zeros(256, dtype=torch.int64, device=dev)
+    cb = hf.DeviceCodebook(ctx)
+    payload = torch.empty(n // 4 + 192 + 64, dtype=torch.int32, device=dev)
+    off = torch.empty(4, dtype=torch.int32, device=dev)
+    out = torch.empty(n, dtype=torch.uint8, device=dev)
+
+    def block(ev=None):
+        if ev: ev[0].record()
+        freq.zero_()
+        stat.accumulate(t, freq)
+        if ev: ev[1].record()
+        system.codebook(freq, hf.HF_MODE_HUFFMAN, out=cb)
+        if ev: ev[2].record()
+        s = system.encode_with(t, cb, payload=payload, chunk_off=off, sync=False)
+        if ev: ev[3].record()
+        decoder.decode(s, out=out, check_stream=False)
+        if ev: ev[4].record()
+        return s
+
+    for _ in range(max(args.warmup, 3)):
+        s = block()
+    ctx.sync()
+    steps = max(args.steps, 20)
+    # latency: one block at a time, the host waits for each
+    lat = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        block()
+        ctx.sync()
+        lat.append(time.perf_counter() - t0)
+    # device time per phase
+    evs = [_events(torch, 5) for _ in range(steps)]
+    for k in range(steps):
+        block(evs[k])
+    torch.cuda.synchronize()
+    ms = _phase_ms(evs, ["hist", "codebook", "encode", "decode"])
+    # throughput: blocks issued back to back, one wait at the end
+    nb = 512
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(nb):
+        block()
+    ctx.sync()
+    batched = time.perf_counter() - t0
+
+    # outside the timed region: the stream against the oracle, byte for byte
+    s = block()
+    ctx.sync()
+    f = orc.aw_symbol_stat(sym, 256, 64)
+    code, lens = orc.rp_system_codebook(f, 64, 0, 16)
+    ref_payload, ref_off = orc.rp_encode(sym, code, lens)
+    total_words = int(off[1].item())
+    gcode, glens, mode, ent = cb.download()
+    ok = (np.array_equal(gcode, code) and np.array_equal(glens, lens)
+          and total_words == ref_payload.size
+          and np.array_equal(payload[:total_words].cpu().numpy().view(np.uint32), ref_payload)
+          and np.array_equal(out.cpu().numpy(), sym))
+    lbar = float((f * lens).sum()) / n
+
+    # the oracle on the same block
+    reps = 4000
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        f2 = orc.aw_symbol_stat(sym, 256, 64)
+        c2, l2 = orc.rp_system_codebook(f2, 64, 0, 16)
+        p2, o2 = orc.rp_encode(sym, c2, l2)
+        orc.rp_decode(p2, o2, n, c2, l2)
+    cpu_s = (time.perf_counter() - t0) / reps
+
+    dev_us = sum(ms.values()) * 1e3
+    dominant = max(ms, key=ms.get)
+    alg = {"hist": n, "codebook": 2048 + 36864, "encode": n * (1 + lbar / 8) + 4,
+           "decode": n * (lbar / 8 + 1) + 4}
+    line = {
+        "metric": bench.METRIC, "value": nb * n / batched / 1e9, "unit": "GB/s", "n_gpus": 1,
+        "steps": steps, "warmup": max(args.warmup, 3), "ms_per_step": batched / nb * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": "config 1: one 4 KB block, 4096 symbols uniform over 0..255 "
+                               "(seed 1), 256-symbol alphabet, Huffman forced, Lmax=16; "
+                               "histogram -> codebook -> encode -> decode per block",
+                   "block_symbols": n},
+        "us_per_block_latency_host": 1e6 * sorted(lat)[len(lat) // 2],
+        "us_per_block_device": dev_us,
+        "us_per_phase_device": {k: v * 1e3 for k, v in ms.items()},
+        "blocks_per_s_back_to_back": nb / batched,
+        "reference_rtl_cycles_per_block_derived_not_simulated": RTL_CYCLES_4K,
+        "reference_rtl_us_per_block_at_1GHz_derived": RTL_CYCLES_4K / 1e3,
+        "compression_mode": mode, "entropy_q16": ent, "bits_per_symbol_ideal": lbar,
+        "bits_per_symbol_stream": 32.0 * total_words / n,
+        "compression_ratio": n / (4 * total_words + 8 + 768),
+        "bit_exact_vs_oracle": bool(ok), "library_sha256_16": bench.library_hash(),
+        "roofline": _roof(alg[dominant], ms[dominant], bound="latency", kernel=dominant,
+                          note="a 4 KB block occupies one wavefront per kernel: every phase is a "
+                               "launch plus a serial chain, not a bandwidth-bound transfer"),
+        "cpu_baseline": {"value": n / cpu_s / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
+                         "sample": f"the same 4 KB block, {reps} repetitions, "
+                                   "histogram+codebook+encode+decode, single thread, gcc -O3",
+                         "us_per_block": cpu_s * 1e6},
+    }
+    print(json.dumps(line), flush=True)
+    if not ok:
+        raise SystemExit("config 1: stream differs from the oracle's")
+
+
+def make_kv_pages(torch, pages, dev, seed=7):
+    """K/V activations N(0,1) x per-channel scale -> fp8 E4M3, 16 tokens x 1024 channels a page."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    scale = torch.exp(torch.randn(1024, generator=g, device=dev) * 0.7)
+    t = torch.empty(pages * CH, dtype=torch.uint8, device=dev)
+    step = 4096
+    for lo in range(0, pages, step):
+        hi = min(pages, lo + step)
+        x = torch.randn((hi - lo) * 16, 1024, generator=g, device=dev) * scale
+        t[lo * CH:hi * CH] = x.to(torch.float8_e4m3fn).view(torch.uint8).reshape(-1)
+    return t
+
+
+def config3(args):
+    import numpy as np
+    import torch
+    from huffman_amd import _lib as L
+    from huffman_amd import api as hf
+    from oracle import oracle as orc
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    pages = args.pages
+    t = make_kv_pages(torch, pages, dev)
+    n = t.numel()
+    ctx = hf.Context(0)
+    lib, h = L.lib(), ctx.handle
+    P = lambda x: C.c_void_p(x.data_ptr())
+    freq = torch.empty(pages * 256, dtype=torch.int32, device=dev)
+    cbs = torch.empty(pages * L.HF_CHUNK_CODEBOOK_BYTES, dtype=torch.uint8, device=dev)
+    payload = torch.empty(n // 4 + pages * 192 + 64, dtype=torch.int32, device=dev)
+    off = torch.empty(pages + 4, dtype=torch.int32, device=dev)
+    out = torch.empty(n, dtype=torch.uint8, device=dev)
+    n_read = min(4096, pages)
+    ids = torch.randperm(pages, device=dev, generator=torch.Generator(device=dev).manual_seed(3))[
+        :n_read].to(torch.int32)
+    slots = torch.randperm(n_read, device=dev,
+                           generator=torch.Generator(device=dev).manual_seed(4)).to(torch.int32)
+    pool = torch.empty(n_read * CH, dtype=torch.uint8, device=dev)
+
+    def step(ev=None):
+        if ev: ev[0].record()
+        L.check(lib.hf_symbol_stat_chunks_dev(h, P(t), n, 0, P(freq)), "stat")
+        if ev: ev[1].record()
+        L.check(lib.hf_system_codebook_chunks_dev(h, P(freq), pages, 1, 0, P(cbs)), "codebooks")
+        if ev: ev[2].record()
+        L.check(lib.hf_encode_chunks(h, P(t), n, 0, P(cbs), None, P(payload), payload.numel(),
+                                     P(off), None), "encode")
+        if ev: ev[3].record()
+        L.check(lib.hf_decode_chunks(h, P(payload), payload.numel(), P(off), None, n, 0, P(cbs),
+                                     None, 0, P(out), 0), "decode")
+        if ev: ev[4].record()
+        L.check(lib.hf_decode_chunks_to(h, P(payload), payload.numel(), P(off), None, n, 0, P(cbs),
+                                        P(ids), P(slots), n_read, P(pool), n_read, 0), "read")
+        if ev: ev[5].record()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    evs = [_events(torch, 6) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(evs[k])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = _phase_ms(evs, ["hist", "codebook", "encode", "decode", "decode_on_read"])
+
+    ctx.sync()  # reports in-kernel errors of the enqueue-only calls
+    total_words = int(off[pages].item()) & 0xFFFFFFFF
+    ok = bool(torch.equal(out, t))
+    ok = ok and bool(torch.equal(pool.view(n_read, CH)[slots.long()],
+                                 t.view(pages, CH)[ids.long()]))
+    lbar_stream = 32.0 * total_words / n
+    fr = freq.view(pages, 256)[:1024].cpu().numpy().astype(np.float64)
+    sample_pages = min(pages, 1024)
+    bits = 0.0
+    for c in range(0, sample_pages, 64):  # ideal bits per symbol from a sample of the records
+        _, lens, _, _ = hf.EntropyAwareHuffmanSystem(ctx=ctx).block_codebook(
+            hf.EncodedStream(n=n, layout=0, dtype=torch.uint8, payload=payload, chunk_off=off,
+                             side=None, codebook=None, chunk_codebooks=cbs), c)
+        bits += float((fr[c] * lens).sum())
+    lbar = bits / (len(range(0, sample_pages, 64)) * CH)
+    comp = 4 * total_words + 4 * (pages + 1) + L.HF_CONTAINER_CHUNK_CODEBOOK_BYTES * pages
+
+    alg = {"hist": float(n), "encode": n * (1 + lbar_stream / 8) + 4.0 * pages,
+           "decode": n * (lbar_stream / 8 + 1) + 4.0 * pages,
+           "decode_on_read": n_read * CH * (lbar_stream / 8 + 1)}
+    roof = {p: _roof(alg[p], ms[p]) for p in alg}
+    dominant = "encode" if ms["encode"] >= ms["decode"] else "decode"
+    line = {
+        "metric": bench.METRIC, "value": n * args.steps / elapsed / 1e9, "unit": "GB/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"config 3: {pages} fp8 E4M3 KV-cache pages of 16 tokens x 1024 "
+                               f"bytes ({n / 1e9:.2f} GB), N(0,1) x per-channel scale, one "
+                               "EntropyAwareTreeBuilder codebook per page (Huffman forced), "
+                               f"decode of all pages plus decode-on-read of {n_read} random pages "
+                               "into a page pool", "pages": pages, "page_bytes": CH},
+        "encode_GBps": n / ((ms["hist"] + ms["codebook"] + ms["encode"]) * 1e-3) / 1e9,
+        "encode_kernel_GBps": n / (ms["encode"] * 1e-3) / 1e9,
+        "decode_GBps": n / (ms["decode"] * 1e-3) / 1e9,
+        "hist_GBps": n / (ms["hist"] * 1e-3) / 1e9,
+        "codebooks_per_s": pages / (ms["codebook"] * 1e-3),
+        "decode_on_read_us": ms["decode_on_read"] * 1e3,
+        "decode_on_read_GBps": n_read * CH / (ms["decode_on_read"] * 1e-3) / 1e9,
+        "compression_ratio": n / comp, "bits_per_symbol_stream": lbar_stream,
+        "bits_per_symbol_ideal_sampled": lbar, "roundtrip_bit_exact": ok,
+        "library_sha256_16": bench.library_hash(),
+        "roofline": dict(roof[dominant], kernel=dominant), "roofline_all": roof,
+    }
+    if not args.no_cpu_baseline:
+        m = min(pages, 49152) * CH  # 0.8 GB: about 15 s of one core
+        sy = t[:m].cpu().numpy()
+        t0 = time.perf_counter()
+        p2, o2, c2, l2 = orc.rp_encode_blocks(sy, 0, payload_words=m // 4 + (m // CH) * 192 + 64)
+        t1 = time.perf_counter()
+        back = orc.rp_decode_blocks(p2, o2, m, c2, l2)
+        t2 = time.perf_counter()
+        assert np.array_equal(back, sy)
+        same = bool(np.array_equal(payload[:p2.size].cpu().numpy().view(np.uint32), p2))
+        line["cpu_baseline"] = {
+            "value": m / (t2 - t0) / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": f"the first {m // CH} pages of the same tensor ({m / 1e9:.2f} GB), per-page "
+                      "histogram+codebook+encode+decode, single thread, gcc -O3",
+            "encode_GBps": m / (t1 - t0) / 1e9, "decode_GBps": m / (t2 - t1) / 1e9,
+            "seconds": t2 - t0, "gpu_payload_equals_oracle_on_sample": same}
+        ok = ok and same
+    print(json.dumps(line), flush=True)
+    if not ok:
+        raise SystemExit("config 3: round trip or oracle mismatch")
+
+
+def _fib_counts(np):
+    f = np.zeros(256, np.uint64)
+    a, b = 1, 1
+    for i in range(256):
+        f[i] = min(a, 1 << 40)
+        a, b = b, a + b
+    return f
+
+
+def _block_counts(np, kind, rng, total=CH):
+    if kind == "fibonacci":
+        p = _fib_counts(np).astype(np.float64)[:40]
+        sym = rng.choice(40, total, p=p / p.sum())
+    elif kind == "geometric":
+        sym = np.minimum(rng.geometric(0.5, total) - 1, 255)
+    elif kind == "one_symbol":
+        sym = np.full(total, 7)
+    elif kind == "two_symbols":
+        sym = (rng.random(total) < 0.001).astype(np.int64)
+    elif kind == "all_equal":
+        sym = np.arange(total) % 256
+    elif kind == "all_zero":
+        return np.zeros(256, np.uint32)
+    else:
+        raise ValueError(kind)
+    return np.bincount(sym, minlength=256).astype(np.uint32)
+
+
+def config5(args):
+    import numpy as np
+    import torch
+    from huffman_amd import _lib as L
+    from huffman_amd import api as hf
+    from oracle import oracle as orc
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    ctx = hf.Context(0)
+    lib, h = L.lib(), ctx.handle
+    P = lambda x: C.c_void_p(x.data_ptr())
+    rng = np.random.default_rng(5)
+    blocks = 65536
+    reps = max(args.steps, 5)
+    shapes = {}
+    ok = True
+    cpu_us = []
+    for kind in ("fibonacci", "geometric", "one_symbol", "two_symbols", "all_equal", "all_zero"):
+        f64 = _fib_counts(np) if kind == "fibonacci" \
+            else _block_counts(np, kind, rng).astype(np.uint64) * 4096  # a 64 MiB block's counts
+        d_f = torch.from_numpy(f64.view(np.int64)).to(dev)
+        cb = hf.DeviceCodebook(ctx)
+        evs = [_events(torch, 2) for _ in range(reps)]
+        for k in range(args.warmup + reps):
+            e = evs[k - args.warmup] if k >= args.warmup else None
+            if e: e[0].record()
+            L.check(lib.hf_system_codebook_dev(h, P(d_f), 1, 0, C.c_void_p(cb.ptr)), "codebook")
+            if e: e[1].record()
+        torch.cuda.synchronize()
+        single_us = min(e[0].elapsed_time(e[1]) for e in evs) * 1e3
+        code, lens, mode, _ = cb.download()
+        ec, el = orc.rp_system_codebook(f64, 64, 0, 16)
+        kraft = float(np.sum(2.0 ** -lens[lens > 0].astype(np.float64)))
+        good = bool(np.array_equal(code, ec) and np.array_equal(lens, el) and lens.max() <= 16
+                    and kraft <= 1.0 + 1e-12)
+        # batched: one codebook per 16384-symbol block, 64 different blocks tiled
+        few = np.stack([_block_counts(np, kind, rng) for _ in range(64)])
+        counts = np.tile(few, (blocks // 64, 1))
+        d_c = torch.from_numpy(counts.view(np.int32).reshape(-1)).to(dev)
+        cbs = torch.empty(blocks * L.HF_CHUNK_CODEBOOK_BYTES, dtype=torch.uint8, device=dev)
+        evs = [_events(torch, 2) for _ in range(reps)]
+        for k in range(args.warmup + reps):
+            e = evs[k - args.warmup] if k >= args.warmup else None
+            if e: e[0].record()
+            L.check(lib.hf_system_codebook_chunks_dev(h, P(d_c), blocks, 1, 0, P(cbs)), "batched")
+            if e: e[1].record()
+        torch.cuda.synchronize()
+        batch_ms = min(e[0].elapsed_time(e[1]) for e in evs)
+        st = hf.EncodedStream(n=blocks * CH, layout=0, dtype=torch.uint8, payload=None,
+                              chunk_off=None, side=None, codebook=None, chunk_codebooks=cbs)
+        for c in (0, 63):
+            bc, bl, _, _ = hf.EntropyAwareHuffmanSystem(ctx=ctx).block_codebook(st, c)
+            oc, ol = orc.rp_system_codebook(few[c].astype(np.uint64), 64, 0, 16)
+            good = good and bool(np.array_equal(bc, oc) and np.array_equal(bl, ol))
+        t0 = time.perf_counter()
+        for _ in range(2000):
+            orc.rp_system_codebook(f64, 64, 0, 16)
+        cu = (time.perf_counter() - t0) / 2000 * 1e6
+        cpu_us.append(cu)
+        shapes[kind] = {"us_per_codebook_single": single_us, "ms_per_65536_batched": batch_ms,
+                        "codebooks_per_s_batched": blocks / (batch_ms * 1e-3),
+                        "max_code_length": int(lens.max()), "kraft_sum": kraft,
+                        "equals_oracle": good, "cpu_oracle_us_per_codebook": cu}
+        ok = ok and good
+    worst = max(shapes.values(), key=lambda d: d["us_per_codebook_single"])
+    slowest_batch = max(d["ms_per_65536_batched"] for d in shapes.values())
+    line = {
+        "metric": "codebook build on degenerate count shapes: codebooks per second (batched "
+                  "per-block path, slowest shape) and microseconds per stream-wide codebook",
+        "value": blocks / (slowest_batch * 1e-3), "unit": "codebooks/s", "n_gpus": 1,
+        "steps": reps, "warmup": args.warmup, "ms_per_step": slowest_batch,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+        "data": "synthetic",
+        "config": {"workload": "config 5: 256 counts -- Fibonacci weights (unconstrained depth far "
+                               "above 16), geometric p = 0.5, one symbol, two symbols 99.9/0.1 %, "
+                               "all equal, all zero; Lmax = 16; one stream-wide codebook (counts "
+                               "of a 64 MiB block) and 65536 per-block codebooks per launch"},
+        "shapes": shapes, "all_equal_oracle": bool(ok),
+        "library_sha256_16": bench.library_hash(),
+        "roofline": _roof(2048 + 36864, worst["us_per_codebook_single"] * 1e-3, bound="latency",
+                          kernel="hf_k_system",
+                          note="one workgroup; the time is a chain of wave-wide steps (sort, "
+                               "merge runs, limiter, tables), not bytes moved"),
+        "cpu_baseline": {"value": 1e6 / max(cpu_us), "unit": "codebooks/s", "cores": 1,
+                         "kind": "port",
+                         "sample": "2000 stream-wide codebooks per shape (sort, tree, limiter, "
+                                   "canonical codes), slowest shape, single thread, gcc -O3"},
+    }
+    print(json.dumps(line), flush=True)
+    if not ok:
+        raise SystemExit("config 5: a codebook differs from the oracle's")

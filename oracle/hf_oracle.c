@@ -679,3 +679,43 @@ int orc_rp_best_mode(const uint64_t* freq_by_symbol, const uint8_t* len_by_symbo
     }
     return bits < 8 * total ? 1 : 0;
 }
+
+/* ---- per-block codebooks ------------------------------------------------------------------
+ * Every chunk of ORC_CHUNK_SYMS symbols is a block of its own, as the reference treats every
+ * block it is fed (symbol_stat.scala:26-33 clears the counters on each `start`): SymbolStat,
+ * the repaired system codebook (Huffman forced) and the packed stream of that chunk alone.
+ * code / len receive nchunks x 256 entries by raw symbol.  chunk_off as in orc_rp_encode. */
+uint64_t orc_rp_encode_blocks(const uint8_t* sym, size_t n, uint64_t min_freq_threshold,
+                              uint16_t* code, uint8_t* len, uint32_t* payload,
+                              uint32_t* chunk_off) {
+    const size_t nchunks = orc_num_chunks(n);
+    uint64_t pos = 0;
+    for (size_t c = 0; c < nchunks; ++c) {
+        const size_t base = c * (size_t)ORC_CHUNK_SYMS;
+        const size_t m = n - base < ORC_CHUNK_SYMS ? n - base : ORC_CHUNK_SYMS;
+        uint64_t freq[256];
+        orc_aw_symbol_stat(sym + base, m, 256, 64, freq);
+        orc_rp_system_codebook(freq, 256, 64, min_freq_threshold, 16, code + c * 256, len + c * 256);
+        uint32_t off2[2];
+        const uint64_t words = orc_rp_encode(sym + base, m, code + c * 256, len + c * 256,
+                                             payload ? payload + pos : NULL, off2);
+        if (chunk_off) chunk_off[c] = (uint32_t)pos;
+        pos += words;
+    }
+    if (chunk_off) chunk_off[nchunks] = (uint32_t)pos;
+    return pos;
+}
+
+int orc_rp_decode_blocks(const uint32_t* payload, const uint32_t* chunk_off, size_t n,
+                         const uint16_t* code, const uint8_t* len, uint8_t* sym_out) {
+    const size_t nchunks = orc_num_chunks(n);
+    for (size_t c = 0; c < nchunks; ++c) {
+        const size_t base = c * (size_t)ORC_CHUNK_SYMS;
+        const size_t m = n - base < ORC_CHUNK_SYMS ? n - base : ORC_CHUNK_SYMS;
+        const uint32_t off2[2] = {0u, chunk_off[c + 1] - chunk_off[c]};
+        if (orc_rp_decode(payload + chunk_off[c], off2, m, code + c * 256, len + c * 256,
+                          sym_out + base) != 0)
+            return -1;
+    }
+    return 0;
+}

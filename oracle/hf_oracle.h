@@ -139,6 +139,16 @@ uint64_t orc_rp_encode(const uint8_t* sym, size_t n, const uint16_t* code, const
 int orc_rp_decode(const uint32_t* payload, const uint32_t* chunk_off, size_t n,
                   const uint16_t* code, const uint8_t* len, uint8_t* sym_out);
 
+/* Per-block codebooks: every chunk of ORC_CHUNK_SYMS symbols is a block of its own (the
+ * reference clears its counters on each `start`, symbol_stat.scala:26-33): SymbolStat, the
+ * repaired system codebook with Huffman forced, and the packed stream, chunk by chunk.
+ * code / len: nchunks x 256 entries by raw symbol.  Returns total words (payload may be NULL). */
+uint64_t orc_rp_encode_blocks(const uint8_t* sym, size_t n, uint64_t min_freq_threshold,
+                              uint16_t* code, uint8_t* len, uint32_t* payload,
+                              uint32_t* chunk_off);
+int orc_rp_decode_blocks(const uint32_t* payload, const uint32_t* chunk_off, size_t n,
+                         const uint16_t* code, const uint8_t* len, uint8_t* sym_out);
+
 size_t orc_num_chunks(size_t n);
 /* Upper bound on payload words for n symbols under any codebook with lengths <= 16. */
 uint64_t orc_payload_bound_words(size_t n);

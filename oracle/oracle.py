@@ -91,6 +91,10 @@ def _declare(l: C.CDLL) -> None:
     l.orc_rp_encode.restype = C.c_uint64
     l.orc_rp_decode.argtypes = [_u32p, _u32p, C.c_size_t, _u16p, _u8p, _u8p]
     l.orc_rp_decode.restype = C.c_int
+    l.orc_rp_encode_blocks.argtypes = [_u8p, C.c_size_t, C.c_uint64, _u16p, _u8p, _u32p, _u32p]
+    l.orc_rp_encode_blocks.restype = C.c_uint64
+    l.orc_rp_decode_blocks.argtypes = [_u32p, _u32p, C.c_size_t, _u16p, _u8p, _u8p]
+    l.orc_rp_decode_blocks.restype = C.c_int
     l.orc_num_chunks.argtypes = [C.c_size_t]
     l.orc_num_chunks.restype = C.c_size_t
     l.orc_payload_bound_words.argtypes = [C.c_size_t]
@@ -357,6 +361,40 @@ def rp_decode(payload, chunk_off, n: int, code, lens) -> np.ndarray:
     out = np.zeros(max(n, 1), np.uint8)
     rc = lib().orc_rp_decode(_p(payload, _u32p), _p(chunk_off, _u32p), n, _p(code, _u16p),
                              _p(lens, _u8p), _p(out, _u8p))
+    if rc != 0:
+        raise ValueError("payload does not decode")
+    return out[:n]
+
+
+def rp_encode_blocks(sym, thr: int = 0, payload_words: int = 0):
+    """Per-block codebooks, Huffman forced: (payload u32, chunk_off u32[nchunks+1],
+    code u16[nchunks, 256], len u8[nchunks, 256]).  `payload_words` > 0 skips the sizing pass
+    (the buffer must be large enough)."""
+    sym = _arr(sym, np.uint8)
+    nch = num_chunks(sym.size)
+    off = np.zeros(nch + 1, np.uint32)
+    code = np.zeros((max(nch, 1), 256), np.uint16)
+    lens = np.zeros((max(nch, 1), 256), np.uint8)
+    if payload_words <= 0:
+        payload_words = int(lib().orc_rp_encode_blocks(_p(sym, _u8p), sym.size, thr,
+                                                       _p(code, _u16p), _p(lens, _u8p), None,
+                                                       _p(off, _u32p)))
+    payload = np.zeros(max(payload_words, 1), np.uint32)
+    total = int(lib().orc_rp_encode_blocks(_p(sym, _u8p), sym.size, thr, _p(code, _u16p),
+                                           _p(lens, _u8p), _p(payload, _u32p), _p(off, _u32p)))
+    return payload[:total], off, code[:nch], lens[:nch]
+
+
+def rp_decode_blocks(payload, chunk_off, n: int, code, lens) -> np.ndarray:
+    payload = _arr(payload, np.uint32)
+    if payload.size == 0:
+        payload = np.zeros(1, np.uint32)
+    chunk_off = _arr(chunk_off, np.uint32)
+    code = _arr(code, np.uint16)
+    lens = _arr(lens, np.uint8)
+    out = np.zeros(max(n, 1), np.uint8)
+    rc = lib().orc_rp_decode_blocks(_p(payload, _u32p), _p(chunk_off, _u32p), n,
+                                    _p(code, _u16p), _p(lens, _u8p), _p(out, _u8p))
     if rc != 0:
         raise ValueError("payload does not decode")
     return out[:n]

@@ -42,6 +42,10 @@ import re
 m = re.search(r'"elements_per_gpu": (\d+)', open(out + "/trace.log").read())
 if m:
     res["elements_per_gpu"] = int(m.group(1))
+# ... and the build they were taken with (bench.py quotes them for this build only)
+m = re.search(r'"library_sha256_16": "([0-9a-f]+)"', open(out + "/trace.log").read())
+if m:
+    res["library_sha256_16"] = m.group(1)
 json.dump(res, open(out + "/summary.json", "w"), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))
 PY
