@@ -30,6 +30,13 @@ trait HuffHip extends Library {
   def hf_symbol_stat(ctx: Pointer, dData: Pointer, n: Long, layout: Int, depth: Int, wtWidth: Int,
                      hFreq: Array[Long]): Int
   def hf_symbol_stat_dev(ctx: Pointer, dData: Pointer, n: Long, layout: Int, dFreq256: Pointer): Int
+  // sub-field front ends (reports/spec.md:22: FP16 / FP8 operands): exponent field -> symbol byte,
+  // the other bits -> packed side stream; layouts 3 (fp16) and 4 (fp8 E4M3)
+  def hf_fields_side_bytes(n: Long, layout: Int): Long
+  def hf_fields_split(ctx: Pointer, dData: Pointer, n: Long, layout: Int, dSym: Pointer,
+                      dSide: Pointer): Int
+  def hf_fields_merge(ctx: Pointer, dSym: Pointer, dSide: Pointer, n: Long, layout: Int,
+                      dOut: Pointer): Int
   // SymbolSort.io: freq_in -> sorted_out (symbol_sort.scala:84-90)
   def hf_symbol_sort(ctx: Pointer, hFreq: Array[Long], depth: Int, hSorted: Array[Long],
                      hRank2Sym: Array[Short]): Int

@@ -18,6 +18,7 @@ HF_OK = 0
 HF_ERR_ARG, HF_ERR_ALIGN, HF_ERR_RANGE, HF_ERR_HIP = -1, -2, -3, -4
 HF_ERR_OVERFLOW, HF_ERR_TIMEOUT, HF_ERR_CORRUPT, HF_ERR_NOMEM = -5, -6, -7, -8
 HF_LAYOUT_U8, HF_LAYOUT_BF16_EXP, HF_LAYOUT_FP8 = 0, 1, 2
+HF_LAYOUT_FP16_EXP, HF_LAYOUT_FP8_E4M3_EXP = 3, 4
 HF_CHUNK_SYMS = 16384
 HF_MAX_CODE_LEN = 16
 HF_MODE_BYPASS, HF_MODE_HUFFMAN, HF_MODE_AUTO, HF_MODE_BEST = 0, 1, 2, 3
@@ -77,6 +78,9 @@ SIGNATURES = {
     "hf_last_hip_error": (C.c_int, [_vp]),
     "hf_symbol_stat": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int, _u64p]),
     "hf_symbol_stat_dev": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, _vp]),
+    "hf_fields_side_bytes": (C.c_uint64, [C.c_uint64, C.c_int]),
+    "hf_fields_split": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, _vp, _vp]),
+    "hf_fields_merge": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_int, _vp]),
     "hf_symbol_sort": (C.c_int, [_vp, _u64p, C.c_int, _u64p, _u16p]),
     "hf_entropy": (C.c_int, [_vp, _u64p, C.c_int, _u32p, _ip]),
     "hf_adaptive_threshold": (C.c_int, [C.c_uint32, C.c_int, C.c_int,

@@ -17,7 +17,7 @@ import torch
 
 from . import _lib as L
 from ._lib import (HF_CHUNK_SYMS, HF_CODEBOOK_DEV_BYTES, HF_LAYOUT_BF16_EXP, HF_LAYOUT_FP8,
-                   HF_LAYOUT_U8, HF_MODE_AUTO, HF_MODE_BEST, HF_MODE_BYPASS, HF_MODE_HUFFMAN, HuffhipError,
+                   HF_LAYOUT_FP8_E4M3_EXP, HF_LAYOUT_FP16_EXP, HF_LAYOUT_U8, HF_MODE_AUTO, HF_MODE_BEST, HF_MODE_BYPASS, HF_MODE_HUFFMAN, HuffhipError,
                    check, hf_entropy_config)
 
 _u8p, _u16p, _u32p, _u64p = (C.POINTER(C.c_uint8), C.POINTER(C.c_uint16), C.POINTER(C.c_uint32),
@@ -47,6 +47,23 @@ def layout_of(t: torch.Tensor) -> int:
     if t.dtype in (getattr(torch, "float8_e4m3fn", None), getattr(torch, "float8_e5m2", None)):
         return HF_LAYOUT_FP8
     raise TypeError(f"unsupported element type {t.dtype}")
+
+
+# layouts that go through hf_fields_split / hf_fields_merge around the byte-symbol kernels
+FIELD_LAYOUTS = (HF_LAYOUT_FP16_EXP, HF_LAYOUT_FP8_E4M3_EXP)
+
+
+def element_bytes(layout: int) -> int:
+    return 2 if layout in (HF_LAYOUT_BF16_EXP, HF_LAYOUT_FP16_EXP) else 1
+
+
+def side_bytes(n: int, layout: int) -> int:
+    """Bytes of the side stream a stream of n elements carries."""
+    if layout == HF_LAYOUT_BF16_EXP:
+        return n
+    if layout in FIELD_LAYOUTS:
+        return int(L.lib().hf_fields_side_bytes(n, layout))
+    return 0
 
 
 def _dev_ptr(t: Optional[torch.Tensor]) -> int:
@@ -379,14 +396,13 @@ class EncodedStream:
         (HF_CONTAINER_CHUNK_CODEBOOK_BYTES = 296 bytes per block: 256 symbol ids, 16 length
         counts, mode, entropy).  Section padding and the header are left to container_bytes()."""
         assert self.total_words is not None
-        side = self.n if self.side is not None else 0
+        side = side_bytes(self.n, self.layout)
         books = 256 * 3 if self.chunk_codebooks is None \
             else L.HF_CONTAINER_CHUNK_CODEBOOK_BYTES * self.nchunks
         return 4 * self.total_words + side + 4 * (self.nchunks + 1) + books
 
     def ratio(self) -> float:
-        raw = self.n * (2 if self.layout == HF_LAYOUT_BF16_EXP else 1)
-        return raw / max(1, self.compressed_bytes())
+        return self.n * element_bytes(self.layout) / max(1, self.compressed_bytes())
 
     # -- container (wire format v1, include/huffhip.h) ---------------------------------------------
     def container_bytes(self) -> int:
@@ -441,10 +457,12 @@ class EncodedStream:
               "hf_container_codebook")
         o_off, o_side, o_pay = int(info.off_chunk_off), int(info.off_side), int(info.off_payload)
         chunk_off = blob[o_off:o_off + 4 * (nch + 1)].view(torch.int32)
-        side = blob[o_side:o_side + n] if info.layout == HF_LAYOUT_BF16_EXP else None
+        nside = side_bytes(n, int(info.layout))
+        side = blob[o_side:o_side + nside] if o_side else None
         payload = blob[o_pay:int(info.total_bytes)].view(torch.int32)  # padded to >= 4 words
         if dtype is None:
-            dtype = torch.bfloat16 if info.layout == HF_LAYOUT_BF16_EXP else torch.uint8
+            dtype = {HF_LAYOUT_BF16_EXP: torch.bfloat16,
+                     HF_LAYOUT_FP16_EXP: torch.float16}.get(int(info.layout), torch.uint8)
         return EncodedStream(n=n, layout=int(info.layout), dtype=dtype, payload=payload,
                              chunk_off=chunk_off, side=side, codebook=cb, total_words=words,
                              chunk_codebooks=cbs)
@@ -519,10 +537,31 @@ class EntropyAwareHuffmanSystem(_Module):
                              chunk_off=chunk_off, side=side if lay == HF_LAYOUT_BF16_EXP else None,
                              codebook=cb, total_words=int(total.value) if sync else None)
 
+    # -- sub-field front end ---------------------------------------------------------------------
+    def split_fields(self, data_in: torch.Tensor, layout: int):
+        """``hf_fields_split``: (symbol bytes uint8[n], packed side stream uint8) of a tensor of
+        fp16 (HF_LAYOUT_FP16_EXP) or fp8 E4M3 (HF_LAYOUT_FP8_E4M3_EXP) elements."""
+        assert layout in FIELD_LAYOUTS and data_in.element_size() == element_bytes(layout)
+        data_in = data_in.contiguous()
+        n = data_in.numel()
+        with torch.cuda.stream(self.ctx.stream):
+            sym = torch.empty(max(16, n), dtype=torch.uint8, device=data_in.device)
+            side = torch.empty(max(16, side_bytes(n, layout)), dtype=torch.uint8,
+                               device=data_in.device)
+        check(L.lib().hf_fields_split(self.ctx.handle, C.c_void_p(_dev_ptr(data_in)), n, layout,
+                                      C.c_void_p(sym.data_ptr()), C.c_void_p(side.data_ptr())),
+              "hf_fields_split")
+        return sym[:n], side[:side_bytes(n, layout)]
+
     # -- whole path ----------------------------------------------------------------------------
     def encode(self, data_in: torch.Tensor, mode: int = HF_MODE_AUTO,
                layout: Optional[int] = None, min_freq_threshold: int = 0) -> EncodedStream:
         data_in = data_in.contiguous()
+        if layout in FIELD_LAYOUTS:
+            sym, side = self.split_fields(data_in, layout)
+            s = self.encode(sym, mode, HF_LAYOUT_U8, min_freq_threshold)
+            s.layout, s.side, s.dtype = layout, side, data_in.dtype
+            return s
         freq = self.histogram(data_in, layout)
         cb = self.codebook(freq, mode, min_freq_threshold)
         return self.encode_with(data_in, cb, layout)
@@ -534,6 +573,11 @@ class EntropyAwareHuffmanSystem(_Module):
         """Every chunk is a block of its own: SymbolStat, SymbolSort, the entropy decision and
         EntropyAwareTreeBuilder run once per chunk, then the chunk is packed with its table."""
         data_in = data_in.contiguous()
+        if layout in FIELD_LAYOUTS:
+            sym, side = self.split_fields(data_in, layout)
+            s = self.encode_blocks(sym, mode, HF_LAYOUT_U8, min_freq_threshold, sync)
+            s.layout, s.side, s.dtype = layout, side, data_in.dtype
+            return s
         lay = layout_of(data_in) if layout is None else layout
         n = data_in.numel()
         dev = data_in.device
@@ -607,11 +651,34 @@ class ParrallelHuffmanDecoder(_Module):  # spelling as in decoder/top_decoder.sc
         if depth != 256 or symWidth != 8 or maxCodeLen != 16:
             raise ValueError("the packed stream is defined for symWidth=8, depth=256, maxCodeLen=16")
 
+    def _merge_fields(self, s: EncodedStream, sym: torch.Tensor,
+                      out: Optional[torch.Tensor]) -> torch.Tensor:
+        """``hf_fields_merge``: decoded symbol bytes + the stream's side fields -> elements."""
+        if out is None:
+            out = torch.empty(max(s.n, 16), dtype=s.dtype, device=sym.device)
+        check(L.lib().hf_fields_merge(self.ctx.handle, C.c_void_p(_dev_ptr(sym)),
+                                      C.c_void_p(_dev_ptr(s.side)), s.n, s.layout,
+                                      C.c_void_p(_dev_ptr(out))), "hf_fields_merge")
+        self.ctx.sync()
+        return out[:s.n]
+
+    @staticmethod
+    def _symbol_view(s: EncodedStream) -> EncodedStream:
+        """The same stream as the byte-symbol kernels see it (sub-field layouts)."""
+        import dataclasses
+        return dataclasses.replace(s, layout=HF_LAYOUT_U8, dtype=torch.uint8, side=None)
+
     def decode_blocks(self, s: EncodedStream, chunk_ids: Optional[torch.Tensor] = None,
                       out: Optional[torch.Tensor] = None, check_stream: bool = True) -> torch.Tensor:
         """Decode a stream with per-block codebooks.  With ``chunk_ids`` (int32 device tensor)
         this is decode-on-read: the listed chunks, in that order, land back to back in ``out``."""
         assert s.chunk_codebooks is not None
+        if s.layout in FIELD_LAYOUTS:
+            if chunk_ids is not None:
+                raise ValueError("decode-on-read of a sub-field stream: decode the symbols with "
+                                 "the HF_LAYOUT_U8 view and join the fields of the pages wanted")
+            sym = self.decode_blocks(self._symbol_view(s), None, None, check_stream)
+            return self._merge_fields(s, sym, out)
         if chunk_ids is None:
             n_out, n_ids = s.n, 0
         else:
@@ -654,6 +721,9 @@ class ParrallelHuffmanDecoder(_Module):  # spelling as in decoder/top_decoder.sc
                check_stream: bool = True) -> torch.Tensor:
         if s.chunk_codebooks is not None:
             return self.decode_blocks(s, None, out, check_stream)
+        if s.layout in FIELD_LAYOUTS:
+            sym = self.decode(self._symbol_view(s), None, check_stream)
+            return self._merge_fields(s, sym, out)
         if out is None:
             out = torch.empty(max(s.n, 16), dtype=s.dtype, device=s.payload.device)
         check(L.lib().hf_decode(self.ctx.handle, C.c_void_p(s.payload.data_ptr()),

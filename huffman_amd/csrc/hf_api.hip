@@ -53,6 +53,11 @@ inline bool layout_ok(int l) {
     return l == HF_LAYOUT_U8 || l == HF_LAYOUT_BF16_EXP || l == HF_LAYOUT_FP8;
 }
 inline int norm_layout(int l) { return l == HF_LAYOUT_FP8 ? HF_LAYOUT_U8 : l; }
+inline bool field_layout(int l) { return l == HF_LAYOUT_FP16_EXP || l == HF_LAYOUT_FP8_E4M3_EXP; }
+// bytes of the side section a stream of n elements carries
+inline uint64_t side_bytes(uint64_t n, int l) {
+    return l == HF_LAYOUT_BF16_EXP ? n : field_layout(l) ? hf_fields_side_bytes_impl(n, l) : 0;
+}
 inline uint64_t mask_w(int W) { return W >= 64 ? ~0ull : ((1ull << W) - 1ull); }
 inline int log2ceil_i(int x) {
     int b = 0;
@@ -281,6 +286,37 @@ int hf_symbol_stat(hf_ctx* ctx, const void* d_data, uint64_t n, int layout, int 
     const uint64_t m = mask_w(wt_width);
     for (int j = 0; j < N; ++j) h_freq[j] = 0;
     for (int s = 0; s < 256; ++s) h_freq[s & (N - 1)] = (h_freq[s & (N - 1)] + ctx->h_freq[s]) & m;
+    return HF_OK;
+}
+
+/* ---- sub-field front ends ------------------------------------------------------------------- */
+uint64_t hf_fields_side_bytes(uint64_t n, int layout) { return hf_fields_side_bytes_impl(n, layout); }
+
+int hf_fields_split(hf_ctx* ctx, const void* d_data, uint64_t n, int layout, uint8_t* d_sym,
+                    uint8_t* d_side) {
+    if (!ctx || !field_layout(layout) || (n && (!d_data || !d_sym || !d_side))) return HF_ERR_ARG;
+    if (!aligned16(d_data) || !aligned16(d_sym) || !aligned16(d_side)) return HF_ERR_ALIGN;
+    if (n > (1ull << 40)) return HF_ERR_RANGE;
+    HF_USE_DEVICE(ctx);
+    tic(ctx);
+    hf_launch_fields_split(d_data, n, layout, d_sym, d_side, ctx->stream);
+    const hipError_t launch_err = hipGetLastError();
+    toc(ctx);
+    HF_HIP(launch_err);
+    return HF_OK;
+}
+
+int hf_fields_merge(hf_ctx* ctx, const uint8_t* d_sym, const uint8_t* d_side, uint64_t n, int layout,
+                    void* d_out) {
+    if (!ctx || !field_layout(layout) || (n && (!d_out || !d_sym || !d_side))) return HF_ERR_ARG;
+    if (!aligned16(d_out) || !aligned16(d_sym) || !aligned16(d_side)) return HF_ERR_ALIGN;
+    if (n > (1ull << 40)) return HF_ERR_RANGE;
+    HF_USE_DEVICE(ctx);
+    tic(ctx);
+    hf_launch_fields_merge(d_sym, d_side, n, layout, d_out, ctx->stream);
+    const hipError_t launch_err = hipGetLastError();
+    toc(ctx);
+    HF_HIP(launch_err);
     return HF_OK;
 }
 
@@ -733,7 +769,8 @@ inline uint64_t up16(uint64_t x) { return (x + 15ull) & ~15ull; }
 // section offsets of a version-1 container; false when the request is not representable
 bool plan_container(uint64_t n, int layout, int kind, uint64_t payload_words,
                     hf_container_info* info) {
-    if (!layout_ok(layout) || (kind != HF_CODEBOOK_STREAM && kind != HF_CODEBOOK_PER_CHUNK))
+    if ((!layout_ok(layout) && !field_layout(layout)) ||
+        (kind != HF_CODEBOOK_STREAM && kind != HF_CODEBOOK_PER_CHUNK))
         return false;
     if (n > (1ull << 40) || payload_words > 0xFFFFFFFFull) return false;
     const uint64_t nchunks = hf_num_chunks(n);
@@ -752,9 +789,9 @@ bool plan_container(uint64_t n, int layout, int kind, uint64_t payload_words,
     off = up16(off);
     info->off_chunk_off = off;
     off = up16(off + 4ull * (nchunks + 1));
-    if (layout == HF_LAYOUT_BF16_EXP) {
+    if (layout == HF_LAYOUT_BF16_EXP || field_layout(layout)) {
         info->off_side = off;
-        off = up16(off + n);
+        off = up16(off + side_bytes(n, layout));
     }
     info->off_payload = off;
     const uint64_t pay = 4ull * payload_words;
@@ -815,9 +852,9 @@ int hf_container_pack(hf_ctx* ctx, hf_container_info* info, const void* d_codebo
     if (after_off > end) HF_HIP(hipMemsetAsync(blob + end, 0, after_off - end, s));
     // side bytes
     if (pl.off_side) {
-        if (pl.n)
-            HF_HIP(hipMemcpyAsync(blob + pl.off_side, d_side, pl.n, hipMemcpyDeviceToDevice, s));
-        end = pl.off_side + pl.n;
+        const uint64_t sb = side_bytes(pl.n, (int)pl.layout);
+        if (sb) HF_HIP(hipMemcpyAsync(blob + pl.off_side, d_side, sb, hipMemcpyDeviceToDevice, s));
+        end = pl.off_side + sb;
         if (pl.off_payload > end) HF_HIP(hipMemsetAsync(blob + end, 0, pl.off_payload - end, s));
     }
     // payload

@@ -138,6 +138,11 @@ void hf_launch_cb_to_wire(const hf_chunk_cb* cbs, uint64_t nchunks, hf_wire_chun
                           hipStream_t s);
 void hf_launch_wire_to_cb(const hf_wire_chunk_cb* in, uint64_t nchunks, hf_chunk_cb* cbs,
                           uint32_t* d_err, hipStream_t s);
+uint64_t hf_fields_side_bytes_impl(uint64_t n, int layout);
+void hf_launch_fields_split(const void* d_data, uint64_t n, int layout, uint8_t* d_sym,
+                            uint8_t* d_side, hipStream_t s);
+void hf_launch_fields_merge(const uint8_t* d_sym, const uint8_t* d_side, uint64_t n, int layout,
+                            void* d_out, hipStream_t s);
 void hf_launch_decode(const uint32_t* d_payload, uint64_t payload_words,
                       const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n, int layout,
                       const hf_cb_dev* cb, void* d_out, uint32_t* d_err, int num_cu,

@@ -42,6 +42,10 @@ extern "C" {
 #define HF_LAYOUT_U8 0       /* symbol = byte                                              */
 #define HF_LAYOUT_BF16_EXP 1 /* symbol = bf16 exponent (w>>7)&0xFF, side byte = sign|mantissa */
 #define HF_LAYOUT_FP8 2      /* fp8 E4M3/E5M2 byte taken whole, same as U8                  */
+/* sub-field layouts: split by hf_fields_split into a symbol stream (coded as HF_LAYOUT_U8) and a
+ * packed side stream, joined again by hf_fields_merge; the container carries them as such */
+#define HF_LAYOUT_FP16_EXP 3     /* fp16: symbol = 5 exponent bits, side field = sign | mantissa */
+#define HF_LAYOUT_FP8_E4M3_EXP 4 /* fp8 E4M3: symbol = sign | exponent, side field = 3 mantissa bits */
 
 /* packed-stream geometry */
 #define HF_CHUNK_SYMS 16384u /* symbols per chunk (one wavefront: 64 lanes x 256 symbols)  */
@@ -104,6 +108,22 @@ int hf_symbol_stat(hf_ctx* ctx, const void* d_data, uint64_t n, int layout, int 
  * ACCUMULATED into (zero it for a fresh block); no synchronisation. */
 int hf_symbol_stat_dev(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
                        uint64_t* d_freq256);
+
+/* ---- sub-field front ends -------------------------------------------------------------------
+ * The reference's spec lists FP16 / FP8 / FP4 operands (reports/spec.md:22) but its RTL takes 8-bit
+ * symbols only (symbol_stat.scala:6-13) and its bit-plane package is an empty file
+ * (bitplane/bitplane.scala:1-4).  These two calls are that front end: hf_fields_split writes one
+ * symbol byte per element (the exponent field: 5 bits of an fp16 value; sign and exponent of an
+ * fp8 E4M3 value) to d_sym and the remaining bits (sign and mantissa, 11 bits; mantissa, 3 bits)
+ * to d_side, bit-packed little endian in element order -- 11 or 3 bytes per 8 elements,
+ * hf_fields_side_bytes(n, layout) in all.  The symbol stream then goes through SymbolStat, the
+ * codebook and the encoder as HF_LAYOUT_U8; hf_fields_merge undoes the split after decoding.
+ * Device pointers, 16-byte aligned; enqueue only. */
+uint64_t hf_fields_side_bytes(uint64_t n, int layout);
+int hf_fields_split(hf_ctx* ctx, const void* d_data, uint64_t n, int layout, uint8_t* d_sym,
+                    uint8_t* d_side);
+int hf_fields_merge(hf_ctx* ctx, const uint8_t* d_sym, const uint8_t* d_side, uint64_t n, int layout,
+                    void* d_out);
 
 /* ---- SymbolSort (symbol_sort.scala:82-148) ------------------------------------------------ */
 /* sorted = counts in descending order (stable).  rank2sym (optional) carries the symbol
@@ -269,7 +289,9 @@ int hf_chunk_codebook_download(hf_ctx* ctx, const void* d_chunk_codebooks, uint6
  *                ranks with code length 1..16 (lengths never decrease with rank, codes are
  *                canonical in rank order), u32 mode, u32 entropy_q16
  *     chunk_off  u32[nchunks + 1]
- *     side       u8[n], HF_LAYOUT_BF16_EXP only
+ *     side       HF_LAYOUT_BF16_EXP: u8[n]; HF_LAYOUT_FP16_EXP, HF_LAYOUT_FP8_E4M3_EXP: the packed
+ *                side fields, hf_fields_side_bytes(n, layout) bytes (the payload then codes the
+ *                symbol bytes of hf_fields_split); absent otherwise
  *     payload    u32[payload_words], padded to at least 16 bytes
  * Every section can be handed to hf_decode / hf_decode_chunks in place (d_blob + offset), so a
  * stored stream is decoded, whole or block by block, without unpacking it. */

@@ -24,12 +24,55 @@ static inline int log2ceil_i(int x) {
 /* front end                                                                                */
 /* ======================================================================================= */
 
+/* Sub-field layouts (reports/spec.md:22 names FP16 / FP8 / FP4 operands; the reference itself
+ * never gets past 8-bit symbols): the symbol is the exponent field, the remaining bits of the
+ * element form a side field of `bits` bits, and the side stream is the dense little-endian
+ * bit-packing of those fields in element order (field i at bits [i * bits, (i + 1) * bits)),
+ * so that every 8 elements fill exactly `bits` bytes. */
+static unsigned side_field_bits(int layout) {
+    return layout == ORC_LAYOUT_FP16_EXP ? 11u : layout == ORC_LAYOUT_FP8_E4M3_EXP ? 3u : 0u;
+}
+
+uint64_t orc_side_bytes(uint64_t n, int layout) {
+    if (layout == ORC_LAYOUT_BF16_EXP) return n;
+    return ((n + 7u) / 8u) * side_field_bits(layout); /* whole groups of 8 elements */
+}
+
+static void put_field(uint8_t* side, size_t i, unsigned bits, unsigned v) {
+    size_t at = i * bits;
+    for (unsigned b = 0; b < bits; ++b, ++at)
+        if ((v >> b) & 1u) side[at >> 3] |= (uint8_t)(1u << (at & 7u));
+}
+
+static unsigned get_field(const uint8_t* side, size_t i, unsigned bits) {
+    size_t at = i * bits;
+    unsigned v = 0;
+    for (unsigned b = 0; b < bits; ++b, ++at) v |= (unsigned)((side[at >> 3] >> (at & 7u)) & 1u) << b;
+    return v;
+}
+
 void orc_symbolize(const void* data, size_t n, int layout, uint8_t* sym, uint8_t* side) {
     if (layout == ORC_LAYOUT_BF16_EXP) {
         const uint16_t* w = (const uint16_t*)data;
         for (size_t i = 0; i < n; ++i) {
             sym[i] = (uint8_t)((w[i] >> 7) & 0xFF);
             if (side) side[i] = (uint8_t)(((w[i] >> 8) & 0x80) | (w[i] & 0x7F));
+        }
+    } else if (layout == ORC_LAYOUT_FP16_EXP) {
+        /* s eeeee mmmmmmmmmm: symbol = the 5 exponent bits, side = sign (bit 10) | mantissa */
+        const uint16_t* w = (const uint16_t*)data;
+        if (side) memset(side, 0, (size_t)orc_side_bytes(n, layout));
+        for (size_t i = 0; i < n; ++i) {
+            sym[i] = (uint8_t)((w[i] >> 10) & 0x1F);
+            if (side) put_field(side, i, 11, ((unsigned)(w[i] >> 15) << 10) | (w[i] & 0x3FFu));
+        }
+    } else if (layout == ORC_LAYOUT_FP8_E4M3_EXP) {
+        /* s eeee mmm: symbol = sign and exponent (5 bits), side = the 3 mantissa bits */
+        const uint8_t* w = (const uint8_t*)data;
+        if (side) memset(side, 0, (size_t)orc_side_bytes(n, layout));
+        for (size_t i = 0; i < n; ++i) {
+            sym[i] = (uint8_t)(w[i] >> 3);
+            if (side) put_field(side, i, 3, w[i] & 7u);
         }
     } else {
         memcpy(sym, data, n);
@@ -42,6 +85,16 @@ void orc_desymbolize(const uint8_t* sym, const uint8_t* side, size_t n, int layo
         for (size_t i = 0; i < n; ++i)
             w[i] = (uint16_t)(((uint16_t)(side[i] & 0x80) << 8) | ((uint16_t)sym[i] << 7) |
                               (side[i] & 0x7F));
+    } else if (layout == ORC_LAYOUT_FP16_EXP) {
+        uint16_t* w = (uint16_t*)out;
+        for (size_t i = 0; i < n; ++i) {
+            const unsigned f = get_field(side, i, 11);
+            w[i] = (uint16_t)(((f >> 10) << 15) | ((unsigned)(sym[i] & 0x1F) << 10) | (f & 0x3FFu));
+        }
+    } else if (layout == ORC_LAYOUT_FP8_E4M3_EXP) {
+        uint8_t* w = (uint8_t*)out;
+        for (size_t i = 0; i < n; ++i)
+            w[i] = (uint8_t)(((unsigned)(sym[i] & 0x1F) << 3) | get_field(side, i, 3));
     } else {
         memcpy(out, sym, n);
     }
@@ -603,9 +656,9 @@ static void container_offsets(uint64_t n, int layout, int kind, uint64_t payload
     off[1] = at;
     at = round16(at + 4u * (nchunks + 1));
     off[2] = 0;
-    if (layout == ORC_LAYOUT_BF16_EXP) {
+    if (orc_side_bytes(n, layout) != 0 || layout == ORC_LAYOUT_BF16_EXP) {
         off[2] = at;
-        at = round16(at + n);
+        at = round16(at + orc_side_bytes(n, layout));
     }
     off[3] = at;
     at += payload_words * 4u < 16u ? 16u : round16(payload_words * 4u);

@@ -38,12 +38,22 @@ extern "C" {
 #define ORC_GROUP 8u          /* consecutive symbols a lane takes per round              */
 #define ORC_ROUNDS 32u        /* rounds per chunk                                        */
 
-enum { ORC_LAYOUT_U8 = 0, ORC_LAYOUT_BF16_EXP = 1, ORC_LAYOUT_FP8 = 2 };
+enum {
+    ORC_LAYOUT_U8 = 0,
+    ORC_LAYOUT_BF16_EXP = 1,
+    ORC_LAYOUT_FP8 = 2,
+    ORC_LAYOUT_FP16_EXP = 3,     /* symbol = 5 exponent bits, side field = sign | 10 mantissa bits */
+    ORC_LAYOUT_FP8_E4M3_EXP = 4, /* symbol = sign | 4 exponent bits, side field = 3 mantissa bits */
+};
 
 /* ---- front end ------------------------------------------------------------------------- */
 /* Split `n` elements into an 8-bit symbol stream and (BF16_EXP only) a raw side byte stream.
  * BF16_EXP: symbol = (w >> 7) & 0xFF (the exponent), side = ((w >> 8) & 0x80) | (w & 0x7F).
  * U8 / FP8: symbol = the byte, no side stream (side may be NULL). */
+/* FP16_EXP / FP8_E4M3_EXP (sub-field layouts; reports/spec.md:22 lists FP16 / FP8 / FP4): the
+ * symbol is the exponent field (with the sign for fp8), the side stream the dense little-endian
+ * bit-packing of the remaining 11 / 3 bits per element in element order, orc_side_bytes() long. */
+uint64_t orc_side_bytes(uint64_t n, int layout);
 void orc_symbolize(const void* data, size_t n, int layout, uint8_t* sym, uint8_t* side);
 void orc_desymbolize(const uint8_t* sym, const uint8_t* side, size_t n, int layout, void* out);
 

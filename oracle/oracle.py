@@ -16,6 +16,7 @@ _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 CHUNK_SYMS = 16384
 LAYOUT_U8, LAYOUT_BF16_EXP, LAYOUT_FP8 = 0, 1, 2
+LAYOUT_FP16_EXP, LAYOUT_FP8_E4M3_EXP = 3, 4
 
 
 def build(force: bool = False) -> str:
@@ -49,6 +50,8 @@ _u64p = C.POINTER(C.c_uint64)
 
 
 def _declare(l: C.CDLL) -> None:
+    l.orc_side_bytes.argtypes = [C.c_uint64, C.c_int]
+    l.orc_side_bytes.restype = C.c_uint64
     l.orc_symbolize.argtypes = [C.c_void_p, C.c_size_t, C.c_int, _u8p, _u8p]
     l.orc_symbolize.restype = None
     l.orc_desymbolize.argtypes = [_u8p, _u8p, C.c_size_t, C.c_int, C.c_void_p]
@@ -110,8 +113,19 @@ def _arr(x, dt) -> np.ndarray:
 
 
 # ---- front end -------------------------------------------------------------------------------
+def side_bytes(n: int, layout: int) -> int:
+    return int(lib().orc_side_bytes(n, layout))
+
+
 def symbolize(data: np.ndarray, layout: int):
     data = np.ascontiguousarray(data)
+    if layout in (LAYOUT_FP16_EXP, LAYOUT_FP8_E4M3_EXP):
+        assert data.dtype == (np.uint16 if layout == LAYOUT_FP16_EXP else np.uint8)
+        n = data.size
+        sym = np.empty(n, np.uint8)
+        side = np.zeros(max(1, side_bytes(n, layout)), np.uint8)
+        lib().orc_symbolize(data.ctypes.data, n, layout, _p(sym, _u8p), _p(side, _u8p))
+        return sym, side[:side_bytes(n, layout)]
     if layout == LAYOUT_BF16_EXP:
         assert data.dtype == np.uint16
         n = data.size
@@ -125,7 +139,12 @@ def symbolize(data: np.ndarray, layout: int):
 
 def desymbolize(sym: np.ndarray, side, layout: int) -> np.ndarray:
     sym = _arr(sym, np.uint8)
-    if layout == LAYOUT_BF16_EXP:
+    if layout == LAYOUT_FP8_E4M3_EXP:
+        side = _arr(side, np.uint8)
+        out = np.empty(sym.size, np.uint8)
+        lib().orc_desymbolize(_p(sym, _u8p), _p(side, _u8p), sym.size, layout, out.ctypes.data)
+        return out
+    if layout in (LAYOUT_BF16_EXP, LAYOUT_FP16_EXP):
         side = _arr(side, np.uint8)
         out = np.empty(sym.size, np.uint16)
         lib().orc_desymbolize(_p(sym, _u8p), _p(side, _u8p), sym.size, layout, out.ctypes.data)

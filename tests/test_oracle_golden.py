@@ -253,3 +253,28 @@ def test_entropy_for_wide_counts_scales_down(orc):
     tot = int(f.sum())
     sh = max(0, tot.bit_length() - 32)
     assert orc.rp_entropy_q16_u64(f) == orc.aw_entropy_q16(f >> np.uint64(sh), 32)
+
+
+def test_sub_field_layouts_round_trip_and_pack_densely(orc):
+    # fp16: symbol = 5 exponent bits, side field = sign | mantissa (11 bits); fp8 E4M3: symbol =
+    # sign | exponent, side field = 3 mantissa bits; side stream = dense little-endian packing
+    rng = np.random.default_rng(1)
+    for n in (1, 7, 8, 9, 1000, 16385):
+        w = rng.integers(0, 65536, n).astype(np.uint16)
+        s, sd = orc.symbolize(w, orc.LAYOUT_FP16_EXP)
+        assert np.array_equal(s, (w >> 10) & 0x1F) and sd.size == ((n + 7) // 8) * 11
+        assert np.array_equal(orc.desymbolize(s, sd, orc.LAYOUT_FP16_EXP), w)
+        b = rng.integers(0, 256, n).astype(np.uint8)
+        s, sd = orc.symbolize(b, orc.LAYOUT_FP8_E4M3_EXP)
+        assert np.array_equal(s, b >> 3) and sd.size == ((n + 7) // 8) * 3
+        assert np.array_equal(orc.desymbolize(s, sd, orc.LAYOUT_FP8_E4M3_EXP), b)
+    # known answers, written out by hand: 0xBC00 = -1.0 (sign 1, exponent 15, mantissa 0)
+    s, sd = orc.symbolize(np.array([0xBC00, 0x3555], np.uint16), orc.LAYOUT_FP16_EXP)
+    assert s.tolist() == [15, 13]
+    assert int.from_bytes(sd.tobytes(), "little") == (0x400) | (0x155 << 11)
+    b = np.array([1, 2, 3, 4, 5, 6, 7, 0xF8], np.uint8)
+    s, sd = orc.symbolize(b, orc.LAYOUT_FP8_E4M3_EXP)
+    assert s.tolist() == [0] * 7 + [31]
+    assert int.from_bytes(sd.tobytes(), "little") == sum(int(x & 7) << (3 * i) for i, x in enumerate(b))
+    assert orc.container_bytes(1000, orc.LAYOUT_FP8_E4M3_EXP, 0, 100) == \
+        orc.container_bytes(1000, orc.LAYOUT_U8, 0, 100) + 384  # 375 side bytes, padded to 16
