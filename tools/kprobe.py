@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--kinds", default="gauss,uniform,geom,fp8")
     ap.add_argument("--no-decode", action="store_true", help="skip decode (experimental encoder builds)")
+    ap.add_argument("--lmax", type=int, default=0,
+                    help="code length limit (tree_depth_limit); the codebook then comes from the "
+                         "module-level builder and is uploaded through MemWrapper")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     ctx = hf.Context(0)
@@ -51,7 +54,16 @@ def main():
             freq.zero_()
             hf.SymbolStat(ctx=ctx).accumulate(w, freq)
             t["hist"].append(ctx.last_kernel_ms())
-            cb = sysm.codebook(freq, hf.HF_MODE_HUFFMAN)
+            if a.lmax:
+                srt = hf.SymbolSort(ctx=ctx)
+                by_rank = srt(freq.cpu().numpy())
+                code, lens = hf.EntropyAwareTreeBuilder(ctx=ctx)(by_rank, 1, a.lmax)
+                mw = hf.MemWrapper(ctx=ctx)
+                for r in range(256):
+                    mw.write(int(srt.rank2sym[r]), int(code[r]), int(lens[r]))
+                cb = mw.to_device()
+            else:
+                cb = sysm.codebook(freq, hf.HF_MODE_HUFFMAN)
             s = sysm.encode_with(w, cb)
             t["enc"].append(ctx.last_kernel_ms())
             if a.no_decode:
