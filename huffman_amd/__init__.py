@@ -3,12 +3,12 @@ liuyuxivapor/huffman Chisel encoder (stats, sort, entropy, tree, adjust, codeboo
 decode).  The compute path is libhuffhip.so (hand-written HIP); see include/huffhip.h.
 """
 from ._lib import (HF_CHUNK_SYMS, HF_CODEBOOK_DEV_BYTES, HF_LAYOUT_BF16_EXP, HF_LAYOUT_FP8,
-                   HF_LAYOUT_FP8_E4M3_EXP, HF_LAYOUT_FP16_EXP, HF_LAYOUT_U8, HF_MODE_AUTO, HF_MODE_BEST, HF_MODE_BYPASS, HF_MODE_HUFFMAN, LIB_PATH,
+                   HF_LAYOUT_BITPLANE8, HF_LAYOUT_FP4_E2M1_EXP, HF_LAYOUT_FP8_E4M3_EXP, HF_LAYOUT_FP16_EXP, HF_LAYOUT_U8, HF_MODE_AUTO, HF_MODE_BEST, HF_MODE_BYPASS, HF_MODE_HUFFMAN, LIB_PATH,
                    HuffhipError, lib)
 
 __all__ = [
     "HF_CHUNK_SYMS", "HF_CODEBOOK_DEV_BYTES", "HF_LAYOUT_BF16_EXP", "HF_LAYOUT_FP8",
-    "HF_LAYOUT_FP8_E4M3_EXP", "HF_LAYOUT_FP16_EXP", "HF_LAYOUT_U8", "HF_MODE_AUTO", "HF_MODE_BEST", "HF_MODE_BYPASS", "HF_MODE_HUFFMAN", "LIB_PATH",
+    "HF_LAYOUT_BITPLANE8", "HF_LAYOUT_FP4_E2M1_EXP", "HF_LAYOUT_FP8_E4M3_EXP", "HF_LAYOUT_FP16_EXP", "HF_LAYOUT_U8", "HF_MODE_AUTO", "HF_MODE_BEST", "HF_MODE_BYPASS", "HF_MODE_HUFFMAN", "LIB_PATH",
     "HuffhipError", "lib",
 ]
 

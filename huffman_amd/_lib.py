@@ -19,6 +19,8 @@ HF_ERR_ARG, HF_ERR_ALIGN, HF_ERR_RANGE, HF_ERR_HIP = -1, -2, -3, -4
 HF_ERR_OVERFLOW, HF_ERR_TIMEOUT, HF_ERR_CORRUPT, HF_ERR_NOMEM = -5, -6, -7, -8
 HF_LAYOUT_U8, HF_LAYOUT_BF16_EXP, HF_LAYOUT_FP8 = 0, 1, 2
 HF_LAYOUT_FP16_EXP, HF_LAYOUT_FP8_E4M3_EXP = 3, 4
+HF_LAYOUT_FP4_E2M1_EXP, HF_LAYOUT_BITPLANE8 = 5, 6
+HF_BITPLANE_BLOCK = 131072
 HF_CHUNK_SYMS = 16384
 HF_MAX_CODE_LEN = 16
 HF_MODE_BYPASS, HF_MODE_HUFFMAN, HF_MODE_AUTO, HF_MODE_BEST = 0, 1, 2, 3

@@ -17,7 +17,7 @@ import torch
 
 from . import _lib as L
 from ._lib import (HF_CHUNK_SYMS, HF_CODEBOOK_DEV_BYTES, HF_LAYOUT_BF16_EXP, HF_LAYOUT_FP8,
-                   HF_LAYOUT_FP8_E4M3_EXP, HF_LAYOUT_FP16_EXP, HF_LAYOUT_U8, HF_MODE_AUTO, HF_MODE_BEST, HF_MODE_BYPASS, HF_MODE_HUFFMAN, HuffhipError,
+                   HF_LAYOUT_BITPLANE8, HF_LAYOUT_FP4_E2M1_EXP, HF_LAYOUT_FP8_E4M3_EXP, HF_LAYOUT_FP16_EXP, HF_LAYOUT_U8, HF_MODE_AUTO, HF_MODE_BEST, HF_MODE_BYPASS, HF_MODE_HUFFMAN, HuffhipError,
                    check, hf_entropy_config)
 
 _u8p, _u16p, _u32p, _u64p = (C.POINTER(C.c_uint8), C.POINTER(C.c_uint16), C.POINTER(C.c_uint32),
@@ -50,7 +50,8 @@ def layout_of(t: torch.Tensor) -> int:
 
 
 # layouts that go through hf_fields_split / hf_fields_merge around the byte-symbol kernels
-FIELD_LAYOUTS = (HF_LAYOUT_FP16_EXP, HF_LAYOUT_FP8_E4M3_EXP)
+FIELD_LAYOUTS = (HF_LAYOUT_FP16_EXP, HF_LAYOUT_FP8_E4M3_EXP, HF_LAYOUT_FP4_E2M1_EXP,
+                 HF_LAYOUT_BITPLANE8)
 
 
 def element_bytes(layout: int) -> int:
@@ -61,7 +62,7 @@ def side_bytes(n: int, layout: int) -> int:
     """Bytes of the side stream a stream of n elements carries."""
     if layout == HF_LAYOUT_BF16_EXP:
         return n
-    if layout in FIELD_LAYOUTS:
+    if layout in FIELD_LAYOUTS:  # (0 for the bit-plane transform)
         return int(L.lib().hf_fields_side_bytes(n, layout))
     return 0
 
@@ -540,18 +541,21 @@ class EntropyAwareHuffmanSystem(_Module):
     # -- sub-field front end ---------------------------------------------------------------------
     def split_fields(self, data_in: torch.Tensor, layout: int):
         """``hf_fields_split``: (symbol bytes uint8[n], packed side stream uint8) of a tensor of
-        fp16 (HF_LAYOUT_FP16_EXP) or fp8 E4M3 (HF_LAYOUT_FP8_E4M3_EXP) elements."""
+        fp16 (HF_LAYOUT_FP16_EXP), fp8 E4M3 (HF_LAYOUT_FP8_E4M3_EXP) or packed fp4 E2M1 pairs
+        (HF_LAYOUT_FP4_E2M1_EXP); HF_LAYOUT_BITPLANE8: (the bytes transposed into bit planes,
+        None)."""
         assert layout in FIELD_LAYOUTS and data_in.element_size() == element_bytes(layout)
         data_in = data_in.contiguous()
         n = data_in.numel()
+        nside = side_bytes(n, layout)
         with torch.cuda.stream(self.ctx.stream):
             sym = torch.empty(max(16, n), dtype=torch.uint8, device=data_in.device)
-            side = torch.empty(max(16, side_bytes(n, layout)), dtype=torch.uint8,
-                               device=data_in.device)
+            side = torch.empty(max(16, nside), dtype=torch.uint8, device=data_in.device) \
+                if layout != HF_LAYOUT_BITPLANE8 else None
         check(L.lib().hf_fields_split(self.ctx.handle, C.c_void_p(_dev_ptr(data_in)), n, layout,
-                                      C.c_void_p(sym.data_ptr()), C.c_void_p(side.data_ptr())),
+                                      C.c_void_p(sym.data_ptr()), C.c_void_p(_dev_ptr(side))),
               "hf_fields_split")
-        return sym[:n], side[:side_bytes(n, layout)]
+        return sym[:n], (side[:nside] if side is not None else None)
 
     # -- whole path ----------------------------------------------------------------------------
     def encode(self, data_in: torch.Tensor, mode: int = HF_MODE_AUTO,

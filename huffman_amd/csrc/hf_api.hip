@@ -53,7 +53,12 @@ inline bool layout_ok(int l) {
     return l == HF_LAYOUT_U8 || l == HF_LAYOUT_BF16_EXP || l == HF_LAYOUT_FP8;
 }
 inline int norm_layout(int l) { return l == HF_LAYOUT_FP8 ? HF_LAYOUT_U8 : l; }
-inline bool field_layout(int l) { return l == HF_LAYOUT_FP16_EXP || l == HF_LAYOUT_FP8_E4M3_EXP; }
+// layouts whose elements are split into a symbol byte and a bit-packed side field
+inline bool field_layout(int l) {
+    return l == HF_LAYOUT_FP16_EXP || l == HF_LAYOUT_FP8_E4M3_EXP || l == HF_LAYOUT_FP4_E2M1_EXP;
+}
+// layouts that pass through hf_fields_split / hf_fields_merge around the byte-symbol kernels
+inline bool front_end_layout(int l) { return field_layout(l) || l == HF_LAYOUT_BITPLANE8; }
 // bytes of the side section a stream of n elements carries
 inline uint64_t side_bytes(uint64_t n, int l) {
     return l == HF_LAYOUT_BF16_EXP ? n : field_layout(l) ? hf_fields_side_bytes_impl(n, l) : 0;
@@ -294,7 +299,8 @@ uint64_t hf_fields_side_bytes(uint64_t n, int layout) { return hf_fields_side_by
 
 int hf_fields_split(hf_ctx* ctx, const void* d_data, uint64_t n, int layout, uint8_t* d_sym,
                     uint8_t* d_side) {
-    if (!ctx || !field_layout(layout) || (n && (!d_data || !d_sym || !d_side))) return HF_ERR_ARG;
+    if (!ctx || !front_end_layout(layout) || (n && (!d_data || !d_sym))) return HF_ERR_ARG;
+    if (field_layout(layout) ? (n && !d_side) : (n % 8 != 0)) return HF_ERR_ARG;
     if (!aligned16(d_data) || !aligned16(d_sym) || !aligned16(d_side)) return HF_ERR_ALIGN;
     if (n > (1ull << 40)) return HF_ERR_RANGE;
     HF_USE_DEVICE(ctx);
@@ -308,7 +314,8 @@ int hf_fields_split(hf_ctx* ctx, const void* d_data, uint64_t n, int layout, uin
 
 int hf_fields_merge(hf_ctx* ctx, const uint8_t* d_sym, const uint8_t* d_side, uint64_t n, int layout,
                     void* d_out) {
-    if (!ctx || !field_layout(layout) || (n && (!d_out || !d_sym || !d_side))) return HF_ERR_ARG;
+    if (!ctx || !front_end_layout(layout) || (n && (!d_out || !d_sym))) return HF_ERR_ARG;
+    if (field_layout(layout) ? (n && !d_side) : (n % 8 != 0)) return HF_ERR_ARG;
     if (!aligned16(d_out) || !aligned16(d_sym) || !aligned16(d_side)) return HF_ERR_ALIGN;
     if (n > (1ull << 40)) return HF_ERR_RANGE;
     HF_USE_DEVICE(ctx);
@@ -769,9 +776,10 @@ inline uint64_t up16(uint64_t x) { return (x + 15ull) & ~15ull; }
 // section offsets of a version-1 container; false when the request is not representable
 bool plan_container(uint64_t n, int layout, int kind, uint64_t payload_words,
                     hf_container_info* info) {
-    if ((!layout_ok(layout) && !field_layout(layout)) ||
+    if ((!layout_ok(layout) && !front_end_layout(layout)) ||
         (kind != HF_CODEBOOK_STREAM && kind != HF_CODEBOOK_PER_CHUNK))
         return false;
+    if (layout == HF_LAYOUT_BITPLANE8 && n % 8 != 0) return false;
     if (n > (1ull << 40) || payload_words > 0xFFFFFFFFull) return false;
     const uint64_t nchunks = hf_num_chunks(n);
     memset(info, 0, sizeof(*info));
@@ -789,7 +797,7 @@ bool plan_container(uint64_t n, int layout, int kind, uint64_t payload_words,
     off = up16(off);
     info->off_chunk_off = off;
     off = up16(off + 4ull * (nchunks + 1));
-    if (layout == HF_LAYOUT_BF16_EXP || field_layout(layout)) {
+    if (layout == HF_LAYOUT_BF16_EXP || side_bytes(n, layout) != 0) {
         info->off_side = off;
         off = up16(off + side_bytes(n, layout));
     }

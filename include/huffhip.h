@@ -46,6 +46,12 @@ extern "C" {
  * packed side stream, joined again by hf_fields_merge; the container carries them as such */
 #define HF_LAYOUT_FP16_EXP 3     /* fp16: symbol = 5 exponent bits, side field = sign | mantissa */
 #define HF_LAYOUT_FP8_E4M3_EXP 4 /* fp8 E4M3: symbol = sign | exponent, side field = 3 mantissa bits */
+#define HF_LAYOUT_FP4_E2M1_EXP 5 /* a byte of two fp4 E2M1: symbol = their sign | exponent fields, side
+                                  * field = the 2 mantissa bits */
+#define HF_LAYOUT_BITPLANE8 6    /* bytes transposed into bit planes, HF_BITPLANE_BLOCK bytes at a
+                                  * time; no side stream; n must be a multiple of 8 */
+#define HF_BITPLANE_BLOCK 131072u /* 8 chunks: with full blocks chunk 8k + p of the symbol stream is
+                                   * bit plane p of data chunks 8k .. 8k + 7 */
 
 /* packed-stream geometry */
 #define HF_CHUNK_SYMS 16384u /* symbols per chunk (one wavefront: 64 lanes x 256 symbols)  */
@@ -114,10 +120,15 @@ int hf_symbol_stat_dev(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
  * symbols only (symbol_stat.scala:6-13) and its bit-plane package is an empty file
  * (bitplane/bitplane.scala:1-4).  These two calls are that front end: hf_fields_split writes one
  * symbol byte per element (the exponent field: 5 bits of an fp16 value; sign and exponent of an
- * fp8 E4M3 value) to d_sym and the remaining bits (sign and mantissa, 11 bits; mantissa, 3 bits)
- * to d_side, bit-packed little endian in element order -- 11 or 3 bytes per 8 elements,
+ * fp8 E4M3 value; the two sign-and-exponent fields of a byte of two fp4 E2M1 values) to d_sym and
+ * the remaining bits (sign and mantissa, 11 bits; mantissa, 3 bits; the two mantissa bits) to
+ * d_side, bit-packed little endian in element order -- 11, 3 or 2 bytes per 8 elements,
  * hf_fields_side_bytes(n, layout) in all.  The symbol stream then goes through SymbolStat, the
  * codebook and the encoder as HF_LAYOUT_U8; hf_fields_merge undoes the split after decoding.
+ * HF_LAYOUT_BITPLANE8 goes through the same two calls: d_sym receives the n bytes transposed into
+ * bit planes (a block of m <= HF_BITPLANE_BLOCK bytes is G = m / 8 groups of 8 consecutive bytes;
+ * symbol block + p * G + g holds bit p of each byte of group g, byte i of the group in bit i),
+ * d_side is not used (NULL) and n must be a multiple of 8 (HF_ERR_ARG otherwise).
  * Device pointers, 16-byte aligned; enqueue only. */
 uint64_t hf_fields_side_bytes(uint64_t n, int layout);
 int hf_fields_split(hf_ctx* ctx, const void* d_data, uint64_t n, int layout, uint8_t* d_sym,
@@ -289,7 +300,7 @@ int hf_chunk_codebook_download(hf_ctx* ctx, const void* d_chunk_codebooks, uint6
  *                ranks with code length 1..16 (lengths never decrease with rank, codes are
  *                canonical in rank order), u32 mode, u32 entropy_q16
  *     chunk_off  u32[nchunks + 1]
- *     side       HF_LAYOUT_BF16_EXP: u8[n]; HF_LAYOUT_FP16_EXP, HF_LAYOUT_FP8_E4M3_EXP: the packed
+ *     side       HF_LAYOUT_BF16_EXP: u8[n]; HF_LAYOUT_FP16_EXP, _FP8_E4M3_EXP, _FP4_E2M1_EXP: the packed
  *                side fields, hf_fields_side_bytes(n, layout) bytes (the payload then codes the
  *                symbol bytes of hf_fields_split); absent otherwise
  *     payload    u32[payload_words], padded to at least 16 bytes

@@ -30,7 +30,10 @@ static inline int log2ceil_i(int x) {
  * bit-packing of those fields in element order (field i at bits [i * bits, (i + 1) * bits)),
  * so that every 8 elements fill exactly `bits` bytes. */
 static unsigned side_field_bits(int layout) {
-    return layout == ORC_LAYOUT_FP16_EXP ? 11u : layout == ORC_LAYOUT_FP8_E4M3_EXP ? 3u : 0u;
+    return layout == ORC_LAYOUT_FP16_EXP       ? 11u
+           : layout == ORC_LAYOUT_FP8_E4M3_EXP ? 3u
+           : layout == ORC_LAYOUT_FP4_E2M1_EXP ? 2u
+                                               : 0u;
 }
 
 uint64_t orc_side_bytes(uint64_t n, int layout) {
@@ -74,6 +77,27 @@ void orc_symbolize(const void* data, size_t n, int layout, uint8_t* sym, uint8_t
             sym[i] = (uint8_t)(w[i] >> 3);
             if (side) put_field(side, i, 3, w[i] & 7u);
         }
+    } else if (layout == ORC_LAYOUT_FP4_E2M1_EXP) {
+        /* two fp4 per byte, s ee m each: symbol = the two sign|exponent fields, side = the two
+         * mantissa bits */
+        const uint8_t* w = (const uint8_t*)data;
+        if (side) memset(side, 0, (size_t)orc_side_bytes(n, layout));
+        for (size_t i = 0; i < n; ++i) {
+            sym[i] = (uint8_t)(((w[i] >> 1) & 7u) | (((w[i] >> 5) & 7u) << 3));
+            if (side) put_field(side, i, 2, (w[i] & 1u) | (((w[i] >> 4) & 1u) << 1));
+        }
+    } else if (layout == ORC_LAYOUT_BITPLANE8) {
+        const uint8_t* w = (const uint8_t*)data;
+        for (size_t b0 = 0; b0 < n; b0 += ORC_BITPLANE_BLOCK) {
+            const size_t m = n - b0 < ORC_BITPLANE_BLOCK ? n - b0 : ORC_BITPLANE_BLOCK;
+            const size_t G = m / 8;
+            for (size_t g = 0; g < G; ++g)
+                for (unsigned p = 0; p < 8; ++p) {
+                    unsigned v = 0;
+                    for (unsigned i = 0; i < 8; ++i) v |= ((w[b0 + 8 * g + i] >> p) & 1u) << i;
+                    sym[b0 + p * G + g] = (uint8_t)v;
+                }
+        }
     } else {
         memcpy(sym, data, n);
     }
@@ -95,6 +119,25 @@ void orc_desymbolize(const uint8_t* sym, const uint8_t* side, size_t n, int layo
         uint8_t* w = (uint8_t*)out;
         for (size_t i = 0; i < n; ++i)
             w[i] = (uint8_t)(((unsigned)(sym[i] & 0x1F) << 3) | get_field(side, i, 3));
+    } else if (layout == ORC_LAYOUT_FP4_E2M1_EXP) {
+        uint8_t* w = (uint8_t*)out;
+        for (size_t i = 0; i < n; ++i) {
+            const unsigned f = get_field(side, i, 2);
+            w[i] = (uint8_t)((f & 1u) | ((unsigned)(sym[i] & 7u) << 1) | (((f >> 1) & 1u) << 4) |
+                             ((unsigned)((sym[i] >> 3) & 7u) << 5));
+        }
+    } else if (layout == ORC_LAYOUT_BITPLANE8) {
+        uint8_t* w = (uint8_t*)out;
+        for (size_t b0 = 0; b0 < n; b0 += ORC_BITPLANE_BLOCK) {
+            const size_t m = n - b0 < ORC_BITPLANE_BLOCK ? n - b0 : ORC_BITPLANE_BLOCK;
+            const size_t G = m / 8;
+            for (size_t g = 0; g < G; ++g)
+                for (unsigned i = 0; i < 8; ++i) {
+                    unsigned v = 0;
+                    for (unsigned p = 0; p < 8; ++p) v |= ((sym[b0 + p * G + g] >> i) & 1u) << p;
+                    w[b0 + 8 * g + i] = (uint8_t)v;
+                }
+        }
     } else {
         memcpy(out, sym, n);
     }

@@ -44,7 +44,10 @@ enum {
     ORC_LAYOUT_FP8 = 2,
     ORC_LAYOUT_FP16_EXP = 3,     /* symbol = 5 exponent bits, side field = sign | 10 mantissa bits */
     ORC_LAYOUT_FP8_E4M3_EXP = 4, /* symbol = sign | 4 exponent bits, side field = 3 mantissa bits */
+    ORC_LAYOUT_FP4_E2M1_EXP = 5, /* a byte = two fp4: symbol = their sign | exponent fields, side = 2 mantissa bits */
+    ORC_LAYOUT_BITPLANE8 = 6,    /* bytes transposed into bit planes, no side stream; n % 8 == 0 */
 };
+#define ORC_BITPLANE_BLOCK (8u * ORC_CHUNK_SYMS) /* bytes transposed together: 8 chunks */
 
 /* ---- front end ------------------------------------------------------------------------- */
 /* Split `n` elements into an 8-bit symbol stream and (BF16_EXP only) a raw side byte stream.
@@ -52,7 +55,16 @@ enum {
  * U8 / FP8: symbol = the byte, no side stream (side may be NULL). */
 /* FP16_EXP / FP8_E4M3_EXP (sub-field layouts; reports/spec.md:22 lists FP16 / FP8 / FP4): the
  * symbol is the exponent field (with the sign for fp8), the side stream the dense little-endian
- * bit-packing of the remaining 11 / 3 bits per element in element order, orc_side_bytes() long. */
+ * bit-packing of the remaining 11 / 3 bits per element in element order, orc_side_bytes() long.
+ * FP4_E2M1_EXP: an element is a byte holding two fp4 values (s ee m, the first in the low
+ * nibble); symbol = (see of the first) | (see of the second) << 3, side field = the two mantissa
+ * bits (first in bit 0), 2 bytes per 8 elements.
+ * BITPLANE8 (bitplane/bitplane.scala is an empty file, reports/spec.md:22 names bit-plane
+ * compression): the bytes are taken in blocks of ORC_BITPLANE_BLOCK (the last one shorter, n a
+ * multiple of 8); a block of m bytes is G = m / 8 groups of 8 consecutive bytes, and symbol
+ * block + p * G + g holds bit p of each byte of group g, byte i of the group in bit i.  With
+ * full blocks chunk 8k + p of the symbol stream is bit plane p of data chunks 8k .. 8k + 7, so
+ * per-chunk codebooks see one plane each.  No side stream. */
 uint64_t orc_side_bytes(uint64_t n, int layout);
 void orc_symbolize(const void* data, size_t n, int layout, uint8_t* sym, uint8_t* side);
 void orc_desymbolize(const uint8_t* sym, const uint8_t* side, size_t n, int layout, void* out);

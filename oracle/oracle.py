@@ -17,6 +17,8 @@ _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 CHUNK_SYMS = 16384
 LAYOUT_U8, LAYOUT_BF16_EXP, LAYOUT_FP8 = 0, 1, 2
 LAYOUT_FP16_EXP, LAYOUT_FP8_E4M3_EXP = 3, 4
+LAYOUT_FP4_E2M1_EXP, LAYOUT_BITPLANE8 = 5, 6
+BITPLANE_BLOCK = 8 * 16384
 
 
 def build(force: bool = False) -> str:
@@ -119,7 +121,12 @@ def side_bytes(n: int, layout: int) -> int:
 
 def symbolize(data: np.ndarray, layout: int):
     data = np.ascontiguousarray(data)
-    if layout in (LAYOUT_FP16_EXP, LAYOUT_FP8_E4M3_EXP):
+    if layout == LAYOUT_BITPLANE8:
+        assert data.dtype == np.uint8 and data.size % 8 == 0
+        sym = np.empty(data.size, np.uint8)
+        lib().orc_symbolize(data.ctypes.data, data.size, layout, _p(sym, _u8p), None)
+        return sym, None
+    if layout in (LAYOUT_FP16_EXP, LAYOUT_FP8_E4M3_EXP, LAYOUT_FP4_E2M1_EXP):
         assert data.dtype == (np.uint16 if layout == LAYOUT_FP16_EXP else np.uint8)
         n = data.size
         sym = np.empty(n, np.uint8)
@@ -139,7 +146,12 @@ def symbolize(data: np.ndarray, layout: int):
 
 def desymbolize(sym: np.ndarray, side, layout: int) -> np.ndarray:
     sym = _arr(sym, np.uint8)
-    if layout == LAYOUT_FP8_E4M3_EXP:
+    if layout == LAYOUT_BITPLANE8:
+        assert sym.size % 8 == 0
+        out = np.empty(sym.size, np.uint8)
+        lib().orc_desymbolize(_p(sym, _u8p), None, sym.size, layout, out.ctypes.data)
+        return out
+    if layout in (LAYOUT_FP8_E4M3_EXP, LAYOUT_FP4_E2M1_EXP):
         side = _arr(side, np.uint8)
         out = np.empty(sym.size, np.uint8)
         lib().orc_desymbolize(_p(sym, _u8p), _p(side, _u8p), sym.size, layout, out.ctypes.data)

@@ -37,7 +37,9 @@ def test_header_constants_match_binding():
     from huffman_amd import _lib
     src = open(HEADER).read()
     for name in ("HF_ABI_VERSION", "HF_CHUNK_SYMS", "HF_MAX_CODE_LEN", "HF_CODEBOOK_DEV_BYTES",
-                 "HF_LAYOUT_U8", "HF_LAYOUT_BF16_EXP", "HF_LAYOUT_FP8", "HF_MODE_BYPASS",
+                 "HF_LAYOUT_U8", "HF_LAYOUT_BF16_EXP", "HF_LAYOUT_FP8", "HF_LAYOUT_FP16_EXP",
+                 "HF_LAYOUT_FP8_E4M3_EXP", "HF_LAYOUT_FP4_E2M1_EXP", "HF_LAYOUT_BITPLANE8",
+                 "HF_BITPLANE_BLOCK", "HF_MODE_BYPASS",
                  "HF_MODE_HUFFMAN", "HF_MODE_AUTO"):
         m = re.search(rf"#define\s+{name}\s+\(?(-?\d+)u?\)?", src)
         assert m, name

@@ -278,3 +278,32 @@ def test_sub_field_layouts_round_trip_and_pack_densely(orc):
     assert int.from_bytes(sd.tobytes(), "little") == sum(int(x & 7) << (3 * i) for i, x in enumerate(b))
     assert orc.container_bytes(1000, orc.LAYOUT_FP8_E4M3_EXP, 0, 100) == \
         orc.container_bytes(1000, orc.LAYOUT_U8, 0, 100) + 384  # 375 side bytes, padded to 16
+
+
+def test_fp4_pairs_and_bit_planes_round_trip_with_known_answers(orc):
+    rng = np.random.default_rng(2)
+    for n in (1, 7, 8, 9, 1000, 16385):
+        b = rng.integers(0, 256, n).astype(np.uint8)
+        s, sd = orc.symbolize(b, orc.LAYOUT_FP4_E2M1_EXP)
+        assert np.array_equal(s, ((b >> 1) & 7) | (((b >> 5) & 7) << 3)) and sd.size == ((n + 7) // 8) * 2
+        assert np.array_equal(orc.desymbolize(s, sd, orc.LAYOUT_FP4_E2M1_EXP), b)
+    # by hand: 0x3B = high nibble 0011 (s 0, ee 01, m 1), low nibble 1011 (s 1, ee 01, m 1)
+    s, sd = orc.symbolize(np.array([0x3B, 0xE0], np.uint8), orc.LAYOUT_FP4_E2M1_EXP)
+    assert s.tolist() == [0b001_101, 0b111_000]
+    assert int.from_bytes(sd.tobytes(), "little") == 0b00_11
+    # bit planes: sizes around the block of 131072 bytes
+    for n in (8, 40, 131072, 131072 + 24, 2 * 131072 + 16384):
+        b = rng.integers(0, 256, n).astype(np.uint8)
+        s, sd = orc.symbolize(b, orc.LAYOUT_BITPLANE8)
+        assert sd is None and s.size == n and orc.side_bytes(n, orc.LAYOUT_BITPLANE8) == 0
+        assert np.array_equal(orc.desymbolize(s, None, orc.LAYOUT_BITPLANE8), b)
+        # the definition, spelled out with numpy for the first block
+        m = min(n, orc.BITPLANE_BLOCK)
+        bits = np.unpackbits(b[:m].reshape(-1, 8)[:, :, None], axis=2, bitorder="little")  # [g, i, p]
+        planes = np.packbits(bits.transpose(2, 0, 1), axis=2, bitorder="little")[:, :, 0]   # [p, g]
+        assert np.array_equal(s[:m], planes.reshape(-1))
+    # by hand: the bytes 0..15 are two groups; plane 0 alternates, plane 3 is the second group only
+    s, _ = orc.symbolize(np.arange(16, dtype=np.uint8), orc.LAYOUT_BITPLANE8)
+    assert s.tolist() == [0xAA, 0xAA, 0xCC, 0xCC, 0xF0, 0xF0, 0x00, 0xFF] + [0] * 8
+    assert orc.container_bytes(1024, orc.LAYOUT_BITPLANE8, 0, 100) == \
+        orc.container_bytes(1024, orc.LAYOUT_U8, 0, 100)

@@ -32,22 +32,27 @@ def main():
          lambda: torch.randn(n, generator=g, device=dev).mul_(0.02).to(torch.float16)),
         ("fp8 sign+exponent", hf.HF_LAYOUT_FP8_E4M3_EXP,
          lambda: torch.randn(n, generator=g, device=dev).to(torch.float8_e4m3fn).view(torch.uint8)),
+        ("fp4 pairs", hf.HF_LAYOUT_FP4_E2M1_EXP,
+         lambda: torch.randint(0, 256, (n,), generator=g, device=dev, dtype=torch.uint8)),
+        ("bit planes", hf.HF_LAYOUT_BITPLANE8,
+         lambda: torch.randint(0, 256, (n,), generator=g, device=dev, dtype=torch.uint8)),
     ):
         w = make()
         eb = w.element_size()
         nside = hf.side_bytes(n, layout)
         sym = torch.empty(n, dtype=torch.uint8, device=dev)
-        side = torch.empty(nside, dtype=torch.uint8, device=dev)
+        side = torch.empty(max(16, nside), dtype=torch.uint8, device=dev)
+        side_ptr = side.data_ptr() if nside else None
         out = torch.empty_like(w)
         ts, tm = [], []
         for _ in range(a.reps):
             hf.check(L.lib().hf_fields_split(ctx.handle, C.c_void_p(w.data_ptr()), n, layout,
-                                             C.c_void_p(sym.data_ptr()), C.c_void_p(side.data_ptr())),
+                                             C.c_void_p(sym.data_ptr()), C.c_void_p(side_ptr)),
                      "hf_fields_split")
             ctx.sync()
             ts.append(ctx.last_kernel_ms())
             hf.check(L.lib().hf_fields_merge(ctx.handle, C.c_void_p(sym.data_ptr()),
-                                             C.c_void_p(side.data_ptr()), n, layout,
+                                             C.c_void_p(side_ptr), n, layout,
                                              C.c_void_p(out.data_ptr())), "hf_fields_merge")
             ctx.sync()
             tm.append(ctx.last_kernel_ms())
