@@ -488,27 +488,29 @@ __device__ __forceinline__ uint32_t system_tree_levels_runs(CbLds& L, const u64*
         L.lq_w[q] = f < thr ? 0ull : f;  // sFilter, entropy_aware_tree_builder.scala:61-66
     }
     wave_sync();
-    int li = 0, ii = N, k = N;  // next leaf, next internal node to take, next node to make
+    // the very first merge finds no internal node waiting and takes two leaves; from then on there
+    // is always one (every merge makes one)
+    if (lane == 0) L.w[N] = L.lq_w[0] + L.lq_w[1];
+    wave_sync();
+    int li = 2, ii = N, k = N + 1;  // next leaf, next internal node to take, next node to make
     while (k < 2 * N - 1) {
+        // Everything a step can need is read in one go (one LDS round trip per step): the two
+        // leaves and the two internal nodes pair `lane` of a run would take.  Lane 0's are the
+        // heads of the two queues.
+        const int lidx = li + 2 * lane, iidx = ii + 2 * lane;
+        const u64 la = L.lq_w[lidx < N ? lidx : N - 1];
+        const u64 lb = L.lq_w[lidx + 1 < N ? lidx + 1 : N - 1];
+        const u64 ia = L.w[iidx < k ? iidx : N];
+        const u64 ib = L.w[iidx + 1 < k ? iidx + 1 : N];
         const bool have_leaf = li < N;
-        const u64 lw = uniform_u64(L.lq_w[have_leaf ? li : N - 1]);
-        if (ii >= k) {
-            // no internal node waits (the very first merge): two leaves
-            const u64 ws = lw + L.lq_w[li + 1];
-            if (lane == 0) L.w[k] = ws;
-            li += 2;
-            ++k;
-            wave_sync();
-            continue;
-        }
-        const u64 H = uniform_u64(L.w[ii]);
+        const u64 lw = uniform_u64(la);  // (clamped to the last leaf when there is none)
+        const u64 H = uniform_u64(ia);
         {   // leaf-leaf run: pair j takes leaves li + 2j and li + 2j + 1
-            const int idx = li + 2 * lane + 1;
-            const bool ok = idx < N && L.lq_w[idx < N ? idx : N - 1] <= H;
+            const bool ok = lidx + 1 < N && lb <= H;
             const u64 m = __ballot(ok);
             const int t = m == ~0ull ? 64 : (int)__builtin_ctzll(~m);
             if (t > 0) {
-                if (lane < t) L.w[k + lane] = L.lq_w[idx - 1] + L.lq_w[idx];
+                if (lane < t) L.w[k + lane] = la + lb;
                 li += 2 * t;
                 k += t;
                 wave_sync();
@@ -526,15 +528,14 @@ __device__ __forceinline__ uint32_t system_tree_levels_runs(CbLds& L, const u64*
             continue;
         }
         {   // internal-internal run over the nodes that exist now: pair j takes ii + 2j, ii + 2j + 1
-            const int idx = ii + 2 * lane + 1;
-            const bool ok = idx < k && (!have_leaf || L.w[idx < k ? idx : ii] < lw);
+            const bool ok = iidx + 1 < k && (!have_leaf || ib < lw);
             const u64 m = __ballot(ok);
             const int t = m == ~0ull ? 64 : (int)__builtin_ctzll(~m);
             if (t > 0) {
                 if (lane < t) {
-                    L.w[k + lane] = L.w[idx - 1] + L.w[idx];
-                    L.parent[idx - 1] = (uint16_t)(k + lane);
-                    L.parent[idx] = (uint16_t)(k + lane);
+                    L.w[k + lane] = ia + ib;
+                    L.parent[iidx] = (uint16_t)(k + lane);
+                    L.parent[iidx + 1] = (uint16_t)(k + lane);
                 }
                 ii += 2 * t;
                 k += t;
@@ -589,9 +590,8 @@ struct TabLds {
     uint16_t sub[256 * 16];
     uint16_t subidx[HF_LUT_SIZE];
     uint32_t lut2[HF_LUT_SIZE];
-    uint32_t wide[128];  // symbols whose first-level span is more than 16 entries (length <= 7)
     uint32_t cnt[4];     // second-level tables named by each wavefront's threads
-    uint32_t n_wide, max_len, hits;
+    uint32_t max_len, hits;
 };
 static_assert(offsetof(hf_cb_dev, lut) % 16 == 0 && offsetof(hf_cb_dev, sub) % 16 == 0 &&
               offsetof(hf_cb_dev, lut2) % 16 == 0, "tables are written 16 bytes at a time");
@@ -599,7 +599,7 @@ static_assert(offsetof(hf_cb_dev, lut) % 16 == 0 && offsetof(hf_cb_dev, sub) % 1
 // T.enc holds the encoder table (code | len << 16 by symbol); every thread of the 256 calls.
 __device__ void build_tables(TabLds& T, hf_cb_dev* cb, const int tid) {
     const int lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) T.n_wide = T.max_len = T.hits = 0;
+    if (tid == 0) T.max_len = T.hits = 0;
     for (int i = tid; i < HF_LUT_SIZE; i += 256) {
         T.lut[i] = 0;
         T.sub[i] = 0;
@@ -609,35 +609,50 @@ __device__ void build_tables(TabLds& T, hf_cb_dev* cb, const int tid) {
     const uint32_t my = T.enc[tid];
     const uint32_t my_len = my >> 16;
     const uint32_t my_code = my & 0xFFFFu;
-    atomicMax(&T.max_len, my_len);
-    if (my_len >= 1 && my_len <= HF_LUT_BITS) {
-        const uint32_t span = 1u << (HF_LUT_BITS - my_len);
-        const uint32_t first = (my_code << (HF_LUT_BITS - my_len)) & (HF_LUT_SIZE - 1);
-        if (span <= 16) {
-            for (uint32_t k = 0; k < span; ++k) T.lut[first + k] = (uint16_t)((tid << 8) | my_len);
-        } else {
-            // (a prefix-free code has at most 2^7 codes of 7 bits or less)
-            const uint32_t slot = atomicAdd(&T.n_wide, 1u);
-            if (slot < 128) T.wide[slot] = (uint32_t)tid;
+    {
+        uint32_t mx = my_len;  // the longest code: one atomic per wavefront
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const uint32_t v = __shfl_xor(mx, o);
+            mx = v > mx ? v : mx;
         }
+        if (lane == 0) atomicMax(&T.max_len, mx);
+    }
+    // First level.  A code of 8..12 bits covers at most 16 entries and its thread writes them.
+    // The span of a shorter code (32..2048 entries) is written by the thread's whole wavefront,
+    // two entries per lane and store, the wavefront's short codes one after the other (what a
+    // span needs travels by readlane, nothing is read back from LDS).
+    const bool fits = my_len >= 1 && my_len <= HF_LUT_BITS;
+    const uint32_t span = fits ? 1u << (HF_LUT_BITS - my_len) : 0u;
+    const uint32_t first = fits ? (my_code << (HF_LUT_BITS - my_len)) & (HF_LUT_SIZE - 1) : 0u;
+    const uint32_t val = ((uint32_t)tid << 8) | my_len;
+    if (fits && span <= 16)
+        for (uint32_t k = 0; k < span; ++k) T.lut[first + k] = (uint16_t)val;
+    for (u64 wide = __ballot(span > 16); wide != 0; wide &= wide - 1) {
+        const int src = (int)__builtin_ctzll(wide);
+        const uint32_t w_first = (uint32_t)__builtin_amdgcn_readlane((int)first, src);
+        const uint32_t w_span = (uint32_t)__builtin_amdgcn_readlane((int)span, src);
+        const uint32_t w_val = (uint32_t)__builtin_amdgcn_readlane((int)val, src);
+        // (a span of 32 or more starts at a multiple of its size: the dwords are aligned)
+        for (uint32_t k = 2u * (uint32_t)lane; k < w_span; k += 128u)
+            *reinterpret_cast<uint32_t*>(&T.lut[w_first + k]) = w_val | (w_val << 16);
     }
     const bool is_long = my_len > HF_LUT_BITS && my_len <= HF_MAX_CODE_LEN;
     const uint32_t my_prefix = is_long ? (my_code >> (my_len - HF_LUT_BITS)) & (HF_LUT_SIZE - 1) : 0;
     if (is_long) T.subidx[my_prefix] = 0;  // mark (every writer stores the same value)
     __syncthreads();
-    // the wide spans, all threads on one span at a time
-    const uint32_t n_wide = T.n_wide < 128u ? T.n_wide : 128u;
-    for (uint32_t w = 0; w < n_wide; ++w) {
-        const uint32_t sy = T.wide[w];
-        const uint32_t e = T.enc[sy];
-        const uint32_t len = e >> 16;
-        const uint32_t span = 1u << (HF_LUT_BITS - len);
-        const uint32_t first = ((e & 0xFFFFu) << (HF_LUT_BITS - len)) & (HF_LUT_SIZE - 1);
-        for (uint32_t k = tid; k < span; k += 256) T.lut[first + k] = (uint16_t)((sy << 8) | len);
+    // number the marked prefixes in ascending order: thread t owns entries 16t .. 16t+15, read as
+    // two 16-byte pieces
+    uint32_t own[8];
+    {
+        const uint4 p0 = reinterpret_cast<const uint4*>(T.subidx)[tid * 2];
+        const uint4 p1 = reinterpret_cast<const uint4*>(T.subidx)[tid * 2 + 1];
+        own[0] = p0.x, own[1] = p0.y, own[2] = p0.z, own[3] = p0.w;
+        own[4] = p1.x, own[5] = p1.y, own[6] = p1.z, own[7] = p1.w;
     }
-    // number the marked prefixes in ascending order: thread t owns entries 16t .. 16t+15
     uint32_t c = 0;
-    for (int k = 0; k < 16; ++k) c += (T.subidx[tid * 16 + k] == 0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c += ((own[k] & 0xFFFFu) == 0) + ((own[k] >> 16) == 0);
     uint32_t incl = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -649,37 +664,47 @@ __device__ void build_tables(TabLds& T, hf_cb_dev* cb, const int tid) {
     uint32_t base = incl - c;
     for (int w = 0; w < wv; ++w) base += T.cnt[w];
     const uint32_t n_sub = T.cnt[0] + T.cnt[1] + T.cnt[2] + T.cnt[3];
-    for (int k = 0; k < 16; ++k) {
-        const int i = tid * 16 + k;
-        if (T.subidx[i] == 0) {
-            T.subidx[i] = (uint16_t)base;
-            T.lut[i] = (uint16_t)(base << 8);  // length 0 = escape to table `base`
-            ++base;
+    if (c != 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = tid * 16 + k;
+            if (((own[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) == 0) {
+                T.subidx[i] = (uint16_t)base;
+                T.lut[i] = (uint16_t)(base << 8);  // length 0 = escape to table `base`
+                ++base;
+            }
         }
     }
     __syncthreads();
     if (is_long) {
         const uint32_t rem = my_len - HF_LUT_BITS;  // 1 .. 4 bits beyond the prefix
-        const uint32_t first = (my_code & ((1u << rem) - 1u)) << (4 - rem);
-        const uint32_t span = 1u << (4 - rem);
+        const uint32_t f2 = (my_code & ((1u << rem) - 1u)) << (4 - rem);
+        const uint32_t span2 = 1u << (4 - rem);
         const uint32_t t = T.subidx[my_prefix];
-        for (uint32_t k = 0; k < span; ++k) T.sub[t * 16 + first + k] = (uint16_t)((tid << 8) | my_len);
+        for (uint32_t k = 0; k < span2; ++k) T.sub[t * 16 + f2 + k] = (uint16_t)val;
     }
     __syncthreads();
+    // The multi-symbol table.  The second lookup is made for every entry (an escape entry has
+    // length 0 and looks itself up), so that the sixteen entries of a thread are sixteen
+    // independent pairs of reads.
     uint32_t hits = 0;
-    for (int i = tid; i < HF_LUT_SIZE; i += 256) {
-        const uint32_t e0 = T.lut[i];
-        const uint32_t len0 = e0 & 0xFFu, sym0 = e0 >> 8;
-        uint32_t v = sym0 << 8;  // escape: the second-level table's number, lengths zero
-        if (len0 != 0) {
-            const uint32_t e1 = T.lut[((uint32_t)i << len0) & (HF_LUT_SIZE - 1)];
-            const uint32_t len1 = e1 & 0xFFu;
-            const bool two = len1 != 0 && len0 + len1 <= HF_LUT_BITS;
-            v = two ? (len0 + len1) | (sym0 << 8) | ((e1 >> 8) << 16) | ((len0 | 0x80u) << 24)
-                    : len0 | (sym0 << 8) | (len0 << 24);
-            hits += two;
-        }
-        T.lut2[i] = v;
+    uint32_t e0[16], e1[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) e0[j] = T.lut[tid + 256 * j];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        e1[j] = T.lut[((uint32_t)(tid + 256 * j) << (e0[j] & 0xFFu)) & (HF_LUT_SIZE - 1)];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t len0 = e0[j] & 0xFFu, sym0 = e0[j] >> 8;
+        const uint32_t len1 = e1[j] & 0xFFu;
+        const bool two = len0 != 0 && len1 != 0 && len0 + len1 <= HF_LUT_BITS;
+        // escape: the second-level table's number, lengths zero
+        const uint32_t v = len0 == 0 ? sym0 << 8
+                           : two     ? (len0 + len1) | (sym0 << 8) | ((e1[j] >> 8) << 16) | ((len0 | 0x80u) << 24)
+                                     : len0 | (sym0 << 8) | (len0 << 24);
+        hits += two;
+        T.lut2[tid + 256 * j] = v;
     }
     hits = hf_wave_sum_u32(hits);
     if (lane == 0) atomicAdd(&T.hits, hits);
