@@ -618,24 +618,33 @@ __device__ void build_tables(TabLds& T, hf_cb_dev* cb, const int tid) {
         }
         if (lane == 0) atomicMax(&T.max_len, mx);
     }
-    // First level.  A code of 8..12 bits covers at most 16 entries and its thread writes them.
-    // The span of a shorter code (32..2048 entries) is written by the thread's whole wavefront,
-    // two entries per lane and store, the wavefront's short codes one after the other (what a
-    // span needs travels by readlane, nothing is read back from LDS).
+    // First level.  A code of 6..12 bits covers at most 64 entries and its thread writes them, 16
+    // bytes at a time from 8 entries on (a span starts at a multiple of its size).  The span of a
+    // shorter code (128..2048 entries) is written by the thread's whole wavefront, eight entries
+    // per lane and store, the wavefront's short codes one after the other (what a span needs
+    // travels by readlane, nothing is read back from LDS).
     const bool fits = my_len >= 1 && my_len <= HF_LUT_BITS;
     const uint32_t span = fits ? 1u << (HF_LUT_BITS - my_len) : 0u;
     const uint32_t first = fits ? (my_code << (HF_LUT_BITS - my_len)) & (HF_LUT_SIZE - 1) : 0u;
     const uint32_t val = ((uint32_t)tid << 8) | my_len;
-    if (fits && span <= 16)
-        for (uint32_t k = 0; k < span; ++k) T.lut[first + k] = (uint16_t)val;
-    for (u64 wide = __ballot(span > 16); wide != 0; wide &= wide - 1) {
+    const uint32_t val2 = val | (val << 16);
+    if (span >= 8 && span <= 64) {
+        for (uint32_t k = 0; k < span; k += 8)
+            *reinterpret_cast<uint4*>(&T.lut[first + k]) = make_uint4(val2, val2, val2, val2);
+    } else if (span == 4) {
+        *reinterpret_cast<uint2*>(&T.lut[first]) = make_uint2(val2, val2);
+    } else if (span == 2) {
+        *reinterpret_cast<uint32_t*>(&T.lut[first]) = val2;
+    } else if (span == 1) {
+        T.lut[first] = (uint16_t)val;
+    }
+    for (u64 wide = __ballot(span > 64); wide != 0; wide &= wide - 1) {
         const int src = (int)__builtin_ctzll(wide);
         const uint32_t w_first = (uint32_t)__builtin_amdgcn_readlane((int)first, src);
         const uint32_t w_span = (uint32_t)__builtin_amdgcn_readlane((int)span, src);
-        const uint32_t w_val = (uint32_t)__builtin_amdgcn_readlane((int)val, src);
-        // (a span of 32 or more starts at a multiple of its size: the dwords are aligned)
-        for (uint32_t k = 2u * (uint32_t)lane; k < w_span; k += 128u)
-            *reinterpret_cast<uint32_t*>(&T.lut[w_first + k]) = w_val | (w_val << 16);
+        const uint32_t w_val2 = (uint32_t)__builtin_amdgcn_readlane((int)val2, src);
+        for (uint32_t k = 8u * (uint32_t)lane; k < w_span; k += 512u)
+            *reinterpret_cast<uint4*>(&T.lut[w_first + k]) = make_uint4(w_val2, w_val2, w_val2, w_val2);
     }
     const bool is_long = my_len > HF_LUT_BITS && my_len <= HF_MAX_CODE_LEN;
     const uint32_t my_prefix = is_long ? (my_code >> (my_len - HF_LUT_BITS)) & (HF_LUT_SIZE - 1) : 0;
