@@ -30,8 +30,9 @@ trait HuffHip extends Library {
   def hf_symbol_stat(ctx: Pointer, dData: Pointer, n: Long, layout: Int, depth: Int, wtWidth: Int,
                      hFreq: Array[Long]): Int
   def hf_symbol_stat_dev(ctx: Pointer, dData: Pointer, n: Long, layout: Int, dFreq256: Pointer): Int
-  // sub-field front ends (reports/spec.md:22: FP16 / FP8 operands): exponent field -> symbol byte,
-  // the other bits -> packed side stream; layouts 3 (fp16) and 4 (fp8 E4M3)
+  // front ends (reports/spec.md:22: FP16 / FP8 / FP4 operands, bit-plane compression): exponent
+  // field -> symbol byte, the other bits -> packed side stream (Layout.FP16_EXP, FP8_E4M3_EXP,
+  // FP4_E2M1_EXP), or bytes -> bit planes (Layout.BITPLANE8: no side stream, n a multiple of 8)
   def hf_fields_side_bytes(n: Long, layout: Int): Long
   def hf_fields_split(ctx: Pointer, dData: Pointer, n: Long, layout: Int, dSym: Pointer,
                       dSide: Pointer): Int
@@ -126,6 +127,13 @@ class EntropyConfig extends Structure {
 }
 
 object HuffHip { lazy val lib: HuffHip = Native.load("huffhip", classOf[HuffHip]) }
+
+// HF_LAYOUT_* and HF_MODE_* of include/huffhip.h
+object Layout {
+  val U8 = 0; val BF16_EXP = 1; val FP8 = 2; val FP16_EXP = 3; val FP8_E4M3_EXP = 4
+  val FP4_E2M1_EXP = 5; val BITPLANE8 = 6
+}
+object Mode { val BYPASS = 0; val HUFFMAN = 1; val AUTO = 2; val BEST = 3 }
 
 /** Software twin of the Chisel SymbolStat: same constructor, `freq_out` of one block. */
 class SymbolStat(val sym_width: Int, val wtWidth: Int, val depth: Int)(implicit ctx: Pointer) {

@@ -163,3 +163,18 @@ def test_scala_binding_names_every_entry_point():
     # and the document points at this file instead of repeating it
     doc = open(os.path.join(root, "INTEGRATION.md")).read()
     assert "trait HuffHip extends Library {" not in doc and "HuffHip.scala" in doc
+
+
+def test_scala_binding_constants_match_the_header():
+    hdr = open(HEADER).read()
+    scala = open(os.path.join(ROOT, "bindings", "scala", "huffman", "hip", "HuffHip.scala")).read()
+    for obj, prefix in (("Layout", "HF_LAYOUT_"), ("Mode", "HF_MODE_")):
+        body = re.search(rf"object {obj} \{{(.*?)\n\}}", scala, re.S)
+        if body is None:
+            body = re.search(rf"object {obj} \{{(.*?)\}}", scala, re.S)
+        pairs = dict((k, int(v)) for k, v in re.findall(r"val (\w+) = (\d+)", body.group(1)))
+        assert pairs, obj
+        for name, value in pairs.items():
+            m = re.search(rf"#define\s+{prefix}{name}\s+(\d+)", hdr)
+            assert m and int(m.group(1)) == value, (obj, name)
+        assert len(pairs) == len(re.findall(rf"#define\s+{prefix}\w+\s+\d+", hdr)), obj
