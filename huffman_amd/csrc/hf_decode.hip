@@ -73,32 +73,20 @@ __device__ __forceinline__ uint32_t lds_address(const void* p) {
 // constants: first level at 0 (the one-symbol table or the multi-symbol one, whichever the
 // codebook calls for), second level behind it, then the wavefronts' payload windows.
 constexpr uint32_t kLutAddr = 0;
-constexpr uint32_t kSubLds = 64;  // second-level tables kept in LDS (2 KiB); a codebook with more
-                                  // of them (up to 256) reads the others from global memory
+// Second-level tables in LDS.  A codebook can have up to 256 of them (8 KiB) and the one-symbol
+// path keeps them all; the multi-symbol path is only taken by codebooks with at most kSubPair
+// (at least 99 % of its 4096 entries resolve two symbols, which leaves fewer than 44 escapes).
+constexpr uint32_t kSubAll = 256;
+constexpr uint32_t kSubPair = 64;
 
-// a code longer than 12 bits: the first-level entry names a 16-entry table for bits 13..16.
-// Tables beyond the ones kept in LDS are read from the device codebook through the scalar cache,
-// one lane at a time: a vector load here, however rare, would make every wait for the side-byte
-// prefetch and the output stores of the symbol loop a wait for all of them.
-template <uint32_t SUB_ADDR>
-__device__ __forceinline__ uint32_t second_level(const uint16_t* __restrict__ sub_global,
-                                                 const uint32_t top, const uint32_t esc,
+// a code longer than 12 bits: the first-level entry names a 16-entry table for bits 13..16
+// (NSUB, a power of two: tables at SUB_ADDR; a table number is masked to it, so that a damaged
+// table cannot send a read past them)
+template <uint32_t SUB_ADDR, uint32_t NSUB>
+__device__ __forceinline__ uint32_t second_level(const uint32_t top, const uint32_t esc,
                                                  uint32_t& len) {
-    const uint32_t idx = ((esc & 0xFFu) << 4) | ((top >> (32 - HF_LUT_BITS - 4)) & 0xFu);
-    uint32_t e2 = 0;
-    if (esc < kSubLds) e2 = lds_u16((idx << 1) + SUB_ADDR);
-    u64 far = __ballot(esc >= kSubLds);
-    while (far) {  // (the active lanes only)
-        const int l = (int)__builtin_ctzll(far);
-        far &= far - 1;
-        const uint32_t il = (uint32_t)__builtin_amdgcn_readlane((int)idx, l);
-        uint32_t w;
-        asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
-                     : "=s"(w)
-                     : "s"(sub_global), "s"((il >> 1) << 2)
-                     : "memory");
-        if (hf_lane() == l) e2 = (il & 1u) ? w >> 16 : w & 0xFFFFu;
-    }
+    const uint32_t idx = ((esc & (NSUB - 1u)) << 4) | ((top >> (32 - HF_LUT_BITS - 4)) & 0xFu);
+    const uint32_t e2 = lds_u16((idx << 1) + SUB_ADDR);
     len = e2 & 0xFFu;
     return e2 >> 8;
 }
@@ -114,7 +102,6 @@ struct DecTables {
     // the escape test once per pair: measured 2 % faster than once per symbol on a stream whose
     // codes all fit the first level, no different on one where 0.4 % of the symbols do not
     static constexpr bool kPairCheck = true;
-    const uint16_t* sub_global;  // the codebook's second-level tables in global memory
 
     // first level, by the next 12 bits (2-byte entries)
     __device__ __forceinline__ uint32_t lookup(const uint32_t top) const {
@@ -122,7 +109,7 @@ struct DecTables {
     }
     __device__ __forceinline__ uint32_t long_code(const uint32_t top, const uint32_t esc,
                                                   uint32_t& len) const {
-        return second_level<SUB_ADDR>(sub_global, top, esc, len);
+        return second_level<SUB_ADDR, kSubAll>(top, esc, len);
     }
 };
 
@@ -132,7 +119,6 @@ struct PairTables {
     static constexpr int kBits = HF_LUT_BITS;
     static constexpr int kStage = kStageWords;
     static constexpr bool kPairs = true;
-    const uint16_t* sub_global;  // the codebook's second-level tables in global memory
 
     // by the next 12 bits (4-byte entries)
     __device__ __forceinline__ uint32_t lookup2(const uint32_t top) const {
@@ -144,7 +130,7 @@ struct PairTables {
     }
     __device__ __forceinline__ uint32_t long_code(const uint32_t top, const uint32_t esc,
                                                   uint32_t& len) const {
-        return second_level<HF_LUT_SIZE * 4>(sub_global, top, esc, len);
+        return second_level<HF_LUT_SIZE * 4, kSubPair>(top, esc, len);
     }
 };
 
@@ -507,13 +493,16 @@ __device__ u64 decode_chunk_tail(const uint32_t* __restrict__ payload, const u64
 // (4-byte entries), so their first level takes 16 KiB; 16-bit elements are bound by HBM either
 // way (the multi-symbol path measured 2 % slower there: twice the table to copy per workgroup,
 // nothing gained per symbol), so their kernel has the one-symbol table only.
+// Second-level tables: the one-symbol path keeps all 256 -- behind the first level, which for byte
+// streams is the upper half of the 16 KiB (the one-symbol table fills the lower half only); the
+// multi-symbol path keeps kSubPair behind its table.
 template <bool PAIRS_POSSIBLE>
 struct DecLds {
     union {
         uint16_t lut[HF_LUT_SIZE];
         uint32_t lut2[PAIRS_POSSIBLE ? HF_LUT_SIZE : HF_LUT_SIZE / 2];
     };
-    uint16_t sub[kSubLds * 16];
+    uint16_t sub[(PAIRS_POSSIBLE ? kSubPair : kSubAll) * 16];
     uint32_t stage[kWaves][kStageWords + kStageSlack];
 };
 
@@ -562,8 +551,11 @@ hf_k_decode(const uint32_t* __restrict__ payload, const uint64_t payload_words,
     extern __shared__ __attribute__((aligned(16))) unsigned char hf_dec_smem[];
     constexpr bool kPairsPossible = LAYOUT != HF_LAYOUT_BF16_EXP;
     typedef DecLds<kPairsPossible> Lds;
-    constexpr uint32_t kSubAddr = (uint32_t)offsetof(Lds, sub);
-    static_assert(offsetof(Lds, lut) == kLutAddr && (!kPairsPossible || kSubAddr == HF_LUT_SIZE * 4),
+    // where the one-symbol path finds its second-level tables / where the multi-symbol path does
+    constexpr uint32_t kSubAddr = (uint32_t)(HF_LUT_SIZE * 2);
+    constexpr uint32_t kSubAddrPair = (uint32_t)offsetof(Lds, sub);
+    static_assert(offsetof(Lds, lut) == kLutAddr && (!kPairsPossible || kSubAddrPair == HF_LUT_SIZE * 4) &&
+                      (kPairsPossible || offsetof(Lds, sub) == kSubAddr),
                   "the tables' LDS addresses are compile-time constants");
     Lds& S = *reinterpret_cast<Lds*>(hf_dec_smem);
     const int lane = hf_lane();
@@ -584,13 +576,14 @@ hf_k_decode(const uint32_t* __restrict__ payload, const uint64_t payload_words,
     // instead of five.
     constexpr int kThreads = kWaves * 64;
     static_assert(kThreads * 16 >= HF_LUT_SIZE * 2 && kThreads * 32 >= HF_LUT_SIZE * 4 &&
-                  kThreads >= (int)kSubLds * 2, "one piece of the one-symbol table, two of the multi-symbol one, "
+                  kThreads >= (int)kSubAll * 2, "one piece of the one-symbol table, two of the multi-symbol one, "
                                    "one of the second level per thread");
     const uint32_t cw = wave < nchunks ? wave : nchunks - 1u;  // (nchunks >= 1)
     const uint32_t o0 = __builtin_amdgcn_readfirstlane(chunk_off[cw]);
     const uint32_t o1 = __builtin_amdgcn_readfirstlane(chunk_off[cw + 1]);
-    const bool pairs = kPairsPossible && (uint32_t)__builtin_amdgcn_readfirstlane(
-                                             (int)cb->pair_hits) >= HF_PAIR_HITS_MIN;
+    const uint32_t n_sub = (uint32_t)__builtin_amdgcn_readfirstlane((int)cb->n_sub);
+    const bool pairs = kPairsPossible && n_sub <= kSubPair &&
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)cb->pair_hits) >= HF_PAIR_HITS_MIN;
     // first level: 512 pieces of the one-symbol table, or 1024 of the multi-symbol one
     const uint4* t_src = pairs ? reinterpret_cast<const uint4*>(cb->lut2)
                                : reinterpret_cast<const uint4*>(cb->lut);
@@ -598,7 +591,7 @@ hf_k_decode(const uint32_t* __restrict__ payload, const uint64_t payload_words,
     const bool has_a = threadIdx.x < t_n, has_b = threadIdx.x + kThreads < t_n;
     const uint4 t_a = t_src[has_a ? threadIdx.x : 0];
     const uint4 t_b = t_src[has_b ? threadIdx.x + kThreads : 0];
-    const uint32_t nsub = cb->n_sub < kSubLds ? cb->n_sub : kSubLds;
+    const uint32_t nsub = n_sub < kSubAll ? n_sub : kSubAll;
     bool staged = wave < nchunks && o1 >= o0 && (uint64_t)o1 <= payload_words;
     uint4 w[kStageWords / 256];
     stage_window_load<kStageWords>(payload, payload_words, staged ? o1 : 0u,
@@ -608,17 +601,16 @@ hf_k_decode(const uint32_t* __restrict__ payload, const uint64_t payload_words,
     if (has_a) reinterpret_cast<uint4*>(S.lut2)[threadIdx.x] = t_a;
     if (has_b) reinterpret_cast<uint4*>(S.lut2)[threadIdx.x + kThreads] = t_b;
     // (a second-level table no first-level entry names is never read, whatever it holds)
-    if (threadIdx.x < kSubLds * 2) reinterpret_cast<uint4*>(S.sub)[threadIdx.x] = t_sub;
+    if (has_sub)
+        reinterpret_cast<uint4*>(hf_dec_smem + (pairs ? kSubAddrPair : kSubAddr))[threadIdx.x] = t_sub;
     stage_window_store<kStageWords>(stg, lane, w);  // (unused when !staged)
     __syncthreads();
     if (kPairsPossible && pairs) {
         PairTables T;
-        T.sub_global = cb->sub;
         decode_chunks_of_wave<LAYOUT>(payload, payload_words, chunk_off, side, n, nchunks, out, T,
                                       stg, err, wave, nwaves, staged, lane);
     } else {
         DecTables<kSubAddr> T;
-        T.sub_global = cb->sub;
         decode_chunks_of_wave<LAYOUT>(payload, payload_words, chunk_off, side, n, nchunks, out, T,
                                       stg, err, wave, nwaves, staged, lane);
     }
