@@ -19,7 +19,7 @@ struct hf_ctx {
     unsigned long long* h_freq;  // pinned
     unsigned long long* d_desc;
     size_t desc_cap;    // entries
-    uint32_t* d_ctl;    // [0] ticket, [1] error bits; 64-byte block
+    uint32_t* d_ctl;    // [1] error bits, [2] total words of the last encode; 64-byte block
     uint32_t* h_ctl;    // pinned, 16 words
     uint32_t* d_spill;
     void* d_cbscratch;  // per-block codebook batch scratch, allocated on first use
@@ -551,38 +551,40 @@ static int encode_common(hf_ctx* ctx, const void* d_data, uint64_t n, int layout
         size_t cap = ctx->desc_cap ? ctx->desc_cap * 2 : (size_t)65536;
         ctx->desc_cap = 0;
         while (cap < nchunks + 2) cap *= 2;
-        HF_HIP(hipMalloc(&ctx->d_desc, cap * sizeof(unsigned long long)));
+        // (two words in front of the descriptors hold the tile ticket, so that one memset clears
+        // everything an encode launch starts from)
+        HF_HIP(hipMalloc(&ctx->d_desc, (cap + 2) * sizeof(unsigned long long)));
         ctx->desc_cap = cap;
     }
     if (nchunks && !ctx->d_spill)
         HF_HIP(hipMalloc(&ctx->d_spill, hf_encode_spill_bytes(ctx->num_cu)));
-    HF_HIP(hipMemsetAsync(ctx->d_ctl, 0, sizeof(uint32_t), ctx->stream));  // the ticket only
     if (nchunks == 0) {
         HF_HIP(hipMemsetAsync(d_chunk_off, 0, sizeof(uint32_t), ctx->stream));
     } else {
-        HF_HIP(hipMemsetAsync(ctx->d_desc, 0, ((nchunks + 1) & ~1ull) * sizeof(unsigned long long),
-                              ctx->stream));
+        // the ticket and the tile descriptors (the error word in d_ctl is sticky and stays)
+        HF_HIP(hipMemsetAsync(ctx->d_desc, 0,
+                              (2 + ((nchunks + 1) & ~1ull)) * sizeof(unsigned long long), ctx->stream));
+        unsigned long long* const desc = ctx->d_desc + 2;
+        uint32_t* const ticket = reinterpret_cast<uint32_t*>(ctx->d_desc);
         tic(ctx);
         if (per_chunk)
             hf_launch_encode_chunks(d_data, n, lay,
                                     reinterpret_cast<const hf_chunk_cb*>(d_codebook), d_side,
-                                    d_payload, payload_cap_words, d_chunk_off, ctx->d_desc,
-                                    ctx->d_ctl, ctx->d_spill, ctx->d_ctl + 1, ctx->num_cu,
-                                    ctx->stream);
+                                    d_payload, payload_cap_words, d_chunk_off, desc, ticket,
+                                    ctx->d_spill, ctx->d_ctl + 1, ctx->num_cu, ctx->stream);
         else
             hf_launch_encode(d_data, n, lay, reinterpret_cast<const hf_cb_dev*>(d_codebook), d_side,
-                             d_payload, payload_cap_words, d_chunk_off, ctx->d_desc, ctx->d_ctl,
-                             ctx->d_spill, ctx->d_ctl + 1, ctx->num_cu, ctx->stream);
+                             d_payload, payload_cap_words, d_chunk_off, desc, ticket, ctx->d_spill,
+                             ctx->d_ctl + 1, ctx->num_cu, ctx->stream);
         const hipError_t launch_err = hipGetLastError();  // before the event record can mask it
         toc(ctx);
         HF_HIP(launch_err);
     }
     if (h_total_words) {
+        // error word and total (the kernel leaves the total in d_ctl[2] too) in one copy
         HF_HIP(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl, 64, hipMemcpyDeviceToHost, ctx->stream));
-        HF_HIP(hipMemcpyAsync(ctx->h_ctl + 8, d_chunk_off + nchunks, sizeof(uint32_t),
-                              hipMemcpyDeviceToHost, ctx->stream));
         HF_HIP(hipStreamSynchronize(ctx->stream));
-        *h_total_words = ctx->h_ctl[8];
+        *h_total_words = nchunks ? ctx->h_ctl[2] : 0;
         return report_kernel_errors(ctx);
     }
     return HF_OK;

@@ -557,7 +557,10 @@ hf_k_encode(const void* __restrict__ data, const uint64_t n, const uint32_t nchu
                 if (c < nchunks) {
                     if (lane == 0) {
                         chunk_off[c] = (uint32_t)base;
-                        if (c == nchunks - 1) chunk_off[nchunks] = (uint32_t)(base + q_total);
+                        if (c == nchunks - 1) {
+                            chunk_off[nchunks] = (uint32_t)(base + q_total);
+                            err[1] = (uint32_t)(base + q_total);  // the total, next to the error word
+                        }
                     }
                     const bool fits = base + q_total <= cap_words && base + q_total <= 0xFFFFFFFFull;
                     if (!fits && lane == 0) atomicOr(err, HF_KERR_OVERFLOW);
