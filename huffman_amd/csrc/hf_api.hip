@@ -70,6 +70,15 @@ inline int log2ceil_i(int x) {
     return b;
 }
 
+__global__ void hf_k_zero_words(uint32_t* p, const uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+void zero_words(uint32_t* d_p, uint64_t n, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(hf_k_zero_words, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_p, n);
+}
+
 int kerr_to_code(uint32_t bits) {
     if (bits & HF_KERR_TIMEOUT) return HF_ERR_TIMEOUT;
     if (bits & HF_KERR_OVERFLOW) return HF_ERR_OVERFLOW;
@@ -558,12 +567,15 @@ static int encode_common(hf_ctx* ctx, const void* d_data, uint64_t n, int layout
     }
     if (nchunks && !ctx->d_spill)
         HF_HIP(hipMalloc(&ctx->d_spill, hf_encode_spill_bytes(ctx->num_cu)));
+    // (cleared by a kernel of the library's own, not by hipMemsetAsync: under stream capture a
+    // memset becomes a graph node of its own kind, and ROCm 7.2 replayed these small ones with a
+    // stale fill pattern from the second replay on, which left the ticket full of garbage)
     if (nchunks == 0) {
-        HF_HIP(hipMemsetAsync(d_chunk_off, 0, sizeof(uint32_t), ctx->stream));
+        zero_words(d_chunk_off, 1, ctx->stream);
     } else {
         // the ticket and the tile descriptors (the error word in d_ctl is sticky and stays)
-        HF_HIP(hipMemsetAsync(ctx->d_desc, 0,
-                              (2 + ((nchunks + 1) & ~1ull)) * sizeof(unsigned long long), ctx->stream));
+        zero_words(reinterpret_cast<uint32_t*>(ctx->d_desc), (2 + ((nchunks + 1) & ~1ull)) * 2,
+                   ctx->stream);
         unsigned long long* const desc = ctx->d_desc + 2;
         uint32_t* const ticket = reinterpret_cast<uint32_t*>(ctx->d_desc);
         tic(ctx);

@@ -1,0 +1,57 @@
+"""The enqueue-only calls under HIP graph capture: histogram -> codebook -> encode -> decode of a
+block captured once on a side stream and replayed on new data.  (After a context's first use none
+of these calls allocates or synchronises; hf_encode with h_total_words = NULL and hf_decode with
+check = 0 only enqueue.)"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("n", [4096, 5 * 16384 + 100])
+def test_block_pipeline_replays_from_a_captured_graph(hf, orc, n):
+    rng = np.random.default_rng(n)
+    first = np.minimum(rng.geometric(0.08, n) - 1, 255).astype(np.uint8)
+    t = torch.from_numpy(first).to(DEV)
+    side = torch.cuda.Stream()
+    ctx = hf.Context(0, stream=side)
+    system, decoder, stat = (hf.EntropyAwareHuffmanSystem(ctx=ctx),
+                             hf.ParrallelHuffmanDecoder(ctx=ctx), hf.SymbolStat(ctx=ctx))
+    freq = torch.zeros(256, dtype=torch.int64, device=DEV)
+    cb = hf.DeviceCodebook(ctx)
+    nch = (n + 16383) // 16384
+    payload = torch.empty(n // 4 + nch * 192 + 64, dtype=torch.int32, device=DEV)
+    off = torch.empty(((nch + 1 + 3) // 4) * 4, dtype=torch.int32, device=DEV)
+    out = torch.empty(n, dtype=torch.uint8, device=DEV)
+
+    def block():
+        freq.zero_()
+        stat.accumulate(t, freq)
+        system.codebook(freq, hf.HF_MODE_HUFFMAN, out=cb)
+        s = system.encode_with(t, cb, payload=payload, chunk_off=off, sync=False)
+        decoder.decode(s, out=out, check_stream=False)
+
+    with torch.cuda.stream(side):
+        block()  # first use: the context's lazy allocations happen here, outside the capture
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        block()
+    for seed in (1, 2):
+        # new contents in the captured input buffer, another distribution each time
+        nxt = rng.integers(0, 256 >> seed, n).astype(np.uint8)
+        t.copy_(torch.from_numpy(nxt).to(DEV))
+        out.zero_()
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        ctx.sync()  # (reports kernel errors kept by the enqueue-only calls, if any)
+        assert np.array_equal(out.cpu().numpy(), nxt)
+        code, lens = orc.rp_system_codebook(orc.aw_symbol_stat(nxt, 256, 64), 64, 0, 16)
+        ref_payload, ref_off = orc.rp_encode(nxt, code, lens)
+        total = int(off[nch].item())
+        assert total == ref_payload.size
+        assert np.array_equal(payload[:total].cpu().numpy().view(np.uint32), ref_payload)
+        assert np.array_equal(off[: nch + 1].cpu().numpy().view(np.uint32), ref_off)
