@@ -55,3 +55,42 @@ def test_block_pipeline_replays_from_a_captured_graph(hf, orc, n):
         assert total == ref_payload.size
         assert np.array_equal(payload[:total].cpu().numpy().view(np.uint32), ref_payload)
         assert np.array_equal(off[: nch + 1].cpu().numpy().view(np.uint32), ref_off)
+
+
+def test_per_block_pipeline_replays_from_a_captured_graph(hf, orc):
+    # per-page histograms -> per-page codebooks -> encode -> decode, captured once
+    pages = 24
+    n = pages * 16384
+    rng = np.random.default_rng(3)
+    t = torch.from_numpy(np.minimum(rng.geometric(0.1, n) - 1, 255).astype(np.uint8)).to(DEV)
+    side = torch.cuda.Stream()
+    ctx = hf.Context(0, stream=side)
+    system, decoder = hf.EntropyAwareHuffmanSystem(ctx=ctx), hf.ParrallelHuffmanDecoder(ctx=ctx)
+    out = torch.empty(n, dtype=torch.uint8, device=DEV)
+    keep = {}
+
+    def block():
+        s = system.encode_blocks(t, mode=hf.HF_MODE_HUFFMAN, sync=False)
+        decoder.decode_blocks(s, out=out, check_stream=False)
+        keep["s"] = s
+
+    with torch.cuda.stream(side):
+        block()
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        block()
+    s = keep["s"]  # the buffers the captured calls write to
+    for seed in (1, 2, 3):
+        nxt = rng.integers(0, 256 >> seed, n).astype(np.uint8)
+        t.copy_(torch.from_numpy(nxt).to(DEV))
+        out.zero_()
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        ctx.sync()
+        assert np.array_equal(out.cpu().numpy(), nxt)
+        payload, off, _, _ = orc.rp_encode_blocks(nxt)
+        total = int(s.chunk_off[pages].item())
+        assert total == payload.size
+        assert np.array_equal(s.payload[:total].cpu().numpy().view(np.uint32), payload)
