@@ -5,10 +5,10 @@ set -eu
 TAG=$1
 cd "$(dirname "$0")/.."
 cp gpurun_out/${TAG}_bench/summary.json profiles/${TAG}_bench_summary.json
-cp "$(find gpurun_out/${TAG}_bench/trace -name '*kernel_stats.csv' | head -n 1)" profiles/${TAG}_bench_kernel_stats.csv
+cp "$(ls -t $(find gpurun_out/${TAG}_bench/trace -name '*kernel_stats.csv') | head -n 1)" profiles/${TAG}_bench_kernel_stats.csv
 for k in gauss fp8 uniform geom blocks; do
   cp gpurun_out/${TAG}_pmc_$k/summary.txt profiles/${TAG}_pmc_${k}_counters.txt
-  cp "$(find gpurun_out/${TAG}_pmc_$k/trace -name '*kernel_stats.csv' | head -n 1)" profiles/${TAG}_pmc_${k}_kernel_stats.csv
+  cp "$(ls -t $(find gpurun_out/${TAG}_pmc_$k/trace -name '*kernel_stats.csv') | head -n 1)" profiles/${TAG}_pmc_${k}_kernel_stats.csv
 done
 for c in 1 2 3 5 4_shard; do cp gpurun_out/${TAG}_line_config$c.json profiles/${TAG}_bench_line_config$c.json; done
 for f in kprobe kprobe_blocks kprobe_codebook kprobe_fields; do
