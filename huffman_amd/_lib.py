@@ -33,6 +33,11 @@ HF_CONTAINER_CHUNK_CODEBOOK_BYTES = 296
 HF_CODEBOOK_STREAM, HF_CODEBOOK_PER_CHUNK = 0, 1
 
 
+def HF_SLOT_WORDS(bits: int) -> int:
+    """Words of a chunk's slot in a slotted stream, from the bits of its codes."""
+    return (bits + 31) // 32 + 126
+
+
 class hf_entropy_config(C.Structure):
     _fields_ = [
         ("encoding_mode", C.c_uint32),
@@ -107,6 +112,11 @@ SIGNATURES = {
                                    C.c_uint64, _vp, C.c_int]),
     "hf_decode_chunks_to": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, C.c_uint64, C.c_int, _vp, _vp,
                                       _vp, C.c_uint64, _vp, C.c_uint64, C.c_int]),
+    "hf_slotted_bound_words": (C.c_uint64, [C.c_uint64]),
+    "hf_encode_chunks_slotted": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, _vp, _vp, _vp, _vp,
+                                           C.c_uint64, _vp, _vp, _u64p]),
+    "hf_decode_chunks_slotted": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp, C.c_uint64, C.c_int,
+                                           _vp, _vp, _vp, C.c_uint64, _vp, C.c_uint64, C.c_int]),
     "hf_chunk_codebook_download": (C.c_int, [_vp, _vp, C.c_uint64, _u16p, _u8p, _ip, _u32p]),
     "hf_container_plan": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_uint64,
                                     C.POINTER(hf_container_info)]),

@@ -386,6 +386,9 @@ class EncodedStream:
     total_words: Optional[int] = None
     chunk_codebooks: Optional[torch.Tensor] = None  # per-block codebook records (uint8)
     chunk_freq: Optional[torch.Tensor] = None       # per-block counts, int32[nchunks * 256]
+    # a slotted stream (hf_encode_chunks_slotted): chunk_off are slot starts, and these the words
+    # each chunk filled of its slot; None for a dense (format-v1) payload
+    chunk_words: Optional[torch.Tensor] = None
 
     @property
     def nchunks(self) -> int:
@@ -400,7 +403,8 @@ class EncodedStream:
         side = side_bytes(self.n, self.layout)
         books = 256 * 3 if self.chunk_codebooks is None \
             else L.HF_CONTAINER_CHUNK_CODEBOOK_BYTES * self.nchunks
-        return 4 * self.total_words + side + 4 * (self.nchunks + 1) + books
+        index = 4 * (self.nchunks + 1) + (4 * self.nchunks if self.chunk_words is not None else 0)
+        return 4 * self.total_words + side + index + books
 
     def ratio(self) -> float:
         return self.n * element_bytes(self.layout) / max(1, self.compressed_bytes())
@@ -409,6 +413,8 @@ class EncodedStream:
     def container_bytes(self) -> int:
         """Size of this stream's container (host arithmetic, nothing is packed)."""
         assert self.total_words is not None, "encode with sync=True first"
+        if self.chunk_words is not None:
+            raise ValueError("a slotted stream is not a format-v1 payload: no container")
         info = L.hf_container_info()
         check(L.lib().hf_container_plan(self.n, self.layout,
                                         1 if self.chunk_codebooks is not None else 0,
@@ -419,6 +425,8 @@ class EncodedStream:
         """One self-describing uint8 device tensor: header, codebook(s), chunk offsets, side
         bytes, payload."""
         assert self.total_words is not None, "encode with sync=True first"
+        if self.chunk_words is not None:
+            raise ValueError("a slotted stream is not a format-v1 payload: no container")
         ctx = ctx if ctx is not None else default_context()
         per_chunk = self.chunk_codebooks is not None
         info = L.hf_container_info()
@@ -573,13 +581,17 @@ class EntropyAwareHuffmanSystem(_Module):
     # -- per-block codebooks (one codebook per 16384-symbol chunk, e.g. a KV-cache page) --------
     def encode_blocks(self, data_in: torch.Tensor, mode: int = HF_MODE_AUTO,
                       layout: Optional[int] = None, min_freq_threshold: int = 0,
-                      sync: bool = True) -> EncodedStream:
+                      sync: bool = True, slotted: bool = False) -> EncodedStream:
         """Every chunk is a block of its own: SymbolStat, SymbolSort, the entropy decision and
-        EntropyAwareTreeBuilder run once per chunk, then the chunk is packed with its table."""
+        EntropyAwareTreeBuilder run once per chunk, then the chunk is packed with its table.
+
+        ``slotted``: every chunk goes to a slot sized from its histogram and codebook before the
+        encoder runs (``hf_encode_chunks_slotted``): 2-4 % more words, written faster; the stream
+        has ``chunk_words`` beside ``chunk_off`` and no container form."""
         data_in = data_in.contiguous()
         if layout in FIELD_LAYOUTS:
             sym, side = self.split_fields(data_in, layout)
-            s = self.encode_blocks(sym, mode, HF_LAYOUT_U8, min_freq_threshold, sync)
+            s = self.encode_blocks(sym, mode, HF_LAYOUT_U8, min_freq_threshold, sync, slotted)
             s.layout, s.side, s.dtype = layout, side, data_in.dtype
             return s
         lay = layout_of(data_in) if layout is None else layout
@@ -595,11 +607,34 @@ class EntropyAwareHuffmanSystem(_Module):
         check(L.lib().hf_system_codebook_chunks_dev(h, C.c_void_p(freq.data_ptr()), nch, mode,
                                                     min_freq_threshold, C.c_void_p(cbs.data_ptr())),
               "hf_system_codebook_chunks_dev")
-        payload = torch.empty(_payload_words_default(n, nch), dtype=torch.int32, device=dev)
         chunk_off = torch.empty(((nch + 1 + 3) // 4) * 4, dtype=torch.int32, device=dev)
         side = torch.empty(max(16, n), dtype=torch.uint8, device=dev) \
             if lay == HF_LAYOUT_BF16_EXP else None
         total = C.c_uint64(0)
+        if slotted:
+            # (slots of the default size hold any block whose codes average <= 8 bits per symbol,
+            # i.e. every block unless min_freq_threshold made its codebook from other counts)
+            chunk_words = torch.empty(((nch + 3) // 4) * 4 + 4, dtype=torch.int32, device=dev)
+
+            def run_slotted(buf):
+                return L.lib().hf_encode_chunks_slotted(
+                    h, C.c_void_p(_dev_ptr(data_in)), n, lay, C.c_void_p(cbs.data_ptr()),
+                    C.c_void_p(freq.data_ptr()), C.c_void_p(_dev_ptr(side)),
+                    C.c_void_p(buf.data_ptr()), buf.numel(), C.c_void_p(chunk_off.data_ptr()),
+                    C.c_void_p(chunk_words.data_ptr()), C.byref(total) if sync else None)
+            payload = torch.empty(max(16, nch * int(L.HF_SLOT_WORDS(HF_CHUNK_SYMS * 8))),
+                                  dtype=torch.int32, device=dev)
+            rc = run_slotted(payload)
+            if rc == L.HF_ERR_OVERFLOW:
+                payload = torch.empty(max(16, int(L.lib().hf_slotted_bound_words(n))),
+                                      dtype=torch.int32, device=dev)
+                rc = run_slotted(payload)
+            check(rc, "hf_encode_chunks_slotted")
+            return EncodedStream(n=n, layout=lay, dtype=data_in.dtype, payload=payload,
+                                 chunk_off=chunk_off, side=side, codebook=None,
+                                 total_words=int(total.value) if sync else None,
+                                 chunk_codebooks=cbs, chunk_freq=freq, chunk_words=chunk_words)
+        payload = torch.empty(_payload_words_default(n, nch), dtype=torch.int32, device=dev)
 
         def run(buf):
             return L.lib().hf_encode_chunks(h, C.c_void_p(_dev_ptr(data_in)), n, lay,
@@ -691,6 +726,15 @@ class ParrallelHuffmanDecoder(_Module):  # spelling as in decoder/top_decoder.sc
             n_out = n_ids * HF_CHUNK_SYMS
         if out is None:
             out = torch.empty(max(n_out, 16), dtype=s.dtype, device=s.payload.device)
+        if s.chunk_words is not None:
+            check(L.lib().hf_decode_chunks_slotted(
+                self.ctx.handle, C.c_void_p(s.payload.data_ptr()), s.payload.numel(),
+                C.c_void_p(s.chunk_off.data_ptr()), C.c_void_p(s.chunk_words.data_ptr()),
+                C.c_void_p(_dev_ptr(s.side)), s.n, s.layout,
+                C.c_void_p(s.chunk_codebooks.data_ptr()), C.c_void_p(_dev_ptr(chunk_ids)), None,
+                n_ids, C.c_void_p(_dev_ptr(out)), 0, 1 if check_stream else 0),
+                "hf_decode_chunks_slotted")
+            return out[:n_out]
         check(L.lib().hf_decode_chunks(self.ctx.handle, C.c_void_p(s.payload.data_ptr()),
                                        s.payload.numel(), C.c_void_p(s.chunk_off.data_ptr()),
                                        C.c_void_p(_dev_ptr(s.side)), s.n, s.layout,
@@ -710,6 +754,16 @@ class ParrallelHuffmanDecoder(_Module):  # spelling as in decoder/top_decoder.sc
         assert chunk_ids.numel() == out_slots.numel()
         assert page_pool.is_cuda and page_pool.is_contiguous() and page_pool.dtype == s.dtype
         assert page_pool.numel() % HF_CHUNK_SYMS == 0
+        if s.chunk_words is not None:
+            check(L.lib().hf_decode_chunks_slotted(
+                self.ctx.handle, C.c_void_p(s.payload.data_ptr()), s.payload.numel(),
+                C.c_void_p(s.chunk_off.data_ptr()), C.c_void_p(s.chunk_words.data_ptr()),
+                C.c_void_p(_dev_ptr(s.side)), s.n, s.layout,
+                C.c_void_p(s.chunk_codebooks.data_ptr()), C.c_void_p(chunk_ids.data_ptr()),
+                C.c_void_p(out_slots.data_ptr()), chunk_ids.numel(),
+                C.c_void_p(page_pool.data_ptr()), page_pool.numel() // HF_CHUNK_SYMS,
+                1 if check_stream else 0), "hf_decode_chunks_slotted")
+            return page_pool
         check(L.lib().hf_decode_chunks_to(self.ctx.handle, C.c_void_p(s.payload.data_ptr()),
                                           s.payload.numel(), C.c_void_p(s.chunk_off.data_ptr()),
                                           C.c_void_p(_dev_ptr(s.side)), s.n, s.layout,

@@ -23,6 +23,8 @@ struct hf_ctx {
     uint32_t* h_ctl;    // pinned, 16 words
     uint32_t* d_spill;
     void* d_cbscratch;  // per-block codebook batch scratch, allocated on first use
+    unsigned long long* d_scan_aux;  // group totals of the slot-offset scan, allocated on first use
+    size_t scan_aux_bytes;
     void* d_static_cbscratch;  // this device's copy of `scratch` below (never freed)
     hipEvent_t ev0, ev1;
     int timing;
@@ -222,6 +224,7 @@ int hf_ctx_destroy(hf_ctx* ctx) {
     if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
     if (ctx->d_spill) (void)hipFree(ctx->d_spill);
     if (ctx->d_cbscratch) (void)hipFree(ctx->d_cbscratch);
+    if (ctx->d_scan_aux) (void)hipFree(ctx->d_scan_aux);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (prev_dev >= 0 && prev_dev != ctx->device) (void)hipSetDevice(prev_dev);
@@ -679,7 +682,8 @@ int hf_encode_chunks(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
 }
 
 static int decode_chunks_common(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
-                                const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n,
+                                const uint32_t* d_chunk_off, const uint32_t* d_chunk_words,
+                                const uint8_t* d_side, uint64_t n,
                                 int layout, const void* d_chunk_codebooks,
                                 const uint32_t* d_chunk_ids, const uint32_t* d_out_slots,
                                 uint64_t n_slots, uint64_t n_ids, void* d_out, int check) {
@@ -692,13 +696,13 @@ static int decode_chunks_common(hf_ctx* ctx, const uint32_t* d_payload, uint64_t
     if (lay == HF_LAYOUT_BF16_EXP && n_work && !d_side) return HF_ERR_ARG;
     if (!aligned16(d_payload) || !aligned16(d_side) || !aligned16(d_out) ||
         !aligned16(d_chunk_off) || !aligned16(d_chunk_codebooks) || !aligned16(d_chunk_ids) ||
-        !aligned16(d_out_slots))
+        !aligned16(d_out_slots) || !aligned16(d_chunk_words))
         return HF_ERR_ALIGN;
     if (n > (1ull << 40) || n_work > 0x7FFFFFFFull || n_slots > 0xFFFFFFFFull) return HF_ERR_RANGE;
     HF_USE_DEVICE(ctx);
     if (n_work) {
         tic(ctx);
-        hf_launch_decode_chunks(d_payload, payload_words, d_chunk_off, d_side, n, lay,
+        hf_launch_decode_chunks(d_payload, payload_words, d_chunk_off, d_chunk_words, d_side, n, lay,
                                 reinterpret_cast<const hf_chunk_cb*>(d_chunk_codebooks),
                                 d_chunk_ids, d_out_slots, n_slots, n_ids, d_out, ctx->d_ctl + 1,
                                 ctx->num_cu, ctx->stream);
@@ -718,8 +722,9 @@ int hf_decode_chunks(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_wo
                      const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n, int layout,
                      const void* d_chunk_codebooks, const uint32_t* d_chunk_ids, uint64_t n_ids,
                      void* d_out, int check) {
-    return decode_chunks_common(ctx, d_payload, payload_words, d_chunk_off, d_side, n, layout,
-                                d_chunk_codebooks, d_chunk_ids, nullptr, 0, n_ids, d_out, check);
+    return decode_chunks_common(ctx, d_payload, payload_words, d_chunk_off, nullptr, d_side, n,
+                                layout, d_chunk_codebooks, d_chunk_ids, nullptr, 0, n_ids, d_out,
+                                check);
 }
 
 int hf_decode_chunks_to(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
@@ -728,9 +733,82 @@ int hf_decode_chunks_to(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload
                         const uint32_t* d_out_slots, uint64_t n_ids, void* d_out, uint64_t n_slots,
                         int check) {
     if (!d_chunk_ids || !d_out_slots) return HF_ERR_ARG;
-    return decode_chunks_common(ctx, d_payload, payload_words, d_chunk_off, d_side, n, layout,
-                                d_chunk_codebooks, d_chunk_ids, d_out_slots, n_slots, n_ids, d_out,
-                                check);
+    return decode_chunks_common(ctx, d_payload, payload_words, d_chunk_off, nullptr, d_side, n,
+                                layout, d_chunk_codebooks, d_chunk_ids, d_out_slots, n_slots, n_ids,
+                                d_out, check);
+}
+
+/* ---- slotted placement of a per-block stream --------------------------------------------------- */
+// (a chunk of 16384 symbols has at most 16384 * 16 bits of codes)
+uint64_t hf_slotted_bound_words(uint64_t n) {
+    return hf_num_chunks(n) * (uint64_t)HF_SLOT_WORDS(HF_CHUNK_SYMS * 16u);
+}
+
+int hf_encode_chunks_slotted(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
+                             const void* d_chunk_codebooks, const uint32_t* d_freq_chunks,
+                             uint8_t* d_side, uint32_t* d_payload, uint64_t payload_cap_words,
+                             uint32_t* d_chunk_off, uint32_t* d_chunk_words,
+                             uint64_t* h_total_words) {
+    if (!ctx || !d_chunk_off || !layout_ok(layout)) return HF_ERR_ARG;
+    if (n && (!d_data || !d_payload || !d_chunk_codebooks || !d_freq_chunks || !d_chunk_words))
+        return HF_ERR_ARG;
+    const int lay = norm_layout(layout);
+    if (lay == HF_LAYOUT_BF16_EXP && n && !d_side) return HF_ERR_ARG;
+    if (!aligned16(d_data) || !aligned16(d_side) || !aligned16(d_payload) ||
+        !aligned16(d_chunk_off) || !aligned16(d_chunk_words) || !aligned16(d_chunk_codebooks) ||
+        !aligned16(d_freq_chunks))
+        return HF_ERR_ALIGN;
+    if (n > (1ull << 40)) return HF_ERR_RANGE;
+    HF_USE_DEVICE(ctx);
+    const uint64_t nchunks = hf_num_chunks(n);
+    const size_t aux = hf_scan_aux_bytes(nchunks + 1);
+    if (aux > ctx->scan_aux_bytes) {
+        if (ctx->d_scan_aux) {
+            HF_HIP(hipStreamSynchronize(ctx->stream));
+            HF_HIP(hipFree(ctx->d_scan_aux));
+            ctx->d_scan_aux = nullptr;
+            ctx->scan_aux_bytes = 0;
+        }
+        size_t cap = (size_t)1 << 16;  // 8 Mi chunks' worth; doubled until it holds this call
+        while (cap < aux) cap *= 2;
+        HF_HIP(hipMalloc(&ctx->d_scan_aux, cap));
+        ctx->scan_aux_bytes = cap;
+    }
+    if (nchunks && !ctx->d_spill)
+        HF_HIP(hipMalloc(&ctx->d_spill, hf_encode_spill_bytes(ctx->num_cu)));
+    if (nchunks == 0) {
+        zero_words(d_chunk_off, 1, ctx->stream);
+    } else {
+        tic(ctx);
+        hf_launch_encode_chunks_slotted(d_data, n, lay,
+                                        reinterpret_cast<const hf_chunk_cb*>(d_chunk_codebooks),
+                                        d_freq_chunks, d_side, d_payload, payload_cap_words,
+                                        d_chunk_off, d_chunk_words, ctx->d_scan_aux, ctx->d_spill,
+                                        ctx->d_ctl + 1, ctx->num_cu, ctx->stream);
+        const hipError_t launch_err = hipGetLastError();
+        toc(ctx);
+        HF_HIP(launch_err);
+    }
+    if (h_total_words) {
+        // error word and total (the scan leaves the last slot offset in d_ctl[2] too) in one copy
+        HF_HIP(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl, 64, hipMemcpyDeviceToHost, ctx->stream));
+        HF_HIP(hipStreamSynchronize(ctx->stream));
+        *h_total_words = nchunks ? ctx->h_ctl[2] : 0;
+        return report_kernel_errors(ctx);
+    }
+    return HF_OK;
+}
+
+int hf_decode_chunks_slotted(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
+                             const uint32_t* d_chunk_off, const uint32_t* d_chunk_words,
+                             const uint8_t* d_side, uint64_t n, int layout,
+                             const void* d_chunk_codebooks, const uint32_t* d_chunk_ids,
+                             const uint32_t* d_out_slots, uint64_t n_ids, void* d_out,
+                             uint64_t n_slots, int check) {
+    if (!d_chunk_words && (d_chunk_ids ? n_ids : hf_num_chunks(n))) return HF_ERR_ARG;
+    return decode_chunks_common(ctx, d_payload, payload_words, d_chunk_off, d_chunk_words, d_side,
+                                n, layout, d_chunk_codebooks, d_chunk_ids, d_out_slots, n_slots,
+                                n_ids, d_out, check);
 }
 
 int hf_chunk_codebook_download(hf_ctx* ctx, const void* d_chunk_codebooks, uint64_t chunk,

@@ -763,7 +763,8 @@ __device__ bool build_chunk_tables(const hf_chunk_cb* __restrict__ ccb, uint16_t
 template <int LAYOUT>
 __global__ __launch_bounds__(kWavesC * 64) void hf_k_decode_chunks(
     const uint32_t* __restrict__ payload, const uint64_t payload_words,
-    const uint32_t* __restrict__ chunk_off, const uint8_t* __restrict__ side, const uint64_t n,
+    const uint32_t* __restrict__ chunk_off, const uint32_t* __restrict__ chunk_words,
+    const uint8_t* __restrict__ side, const uint64_t n,
     const uint32_t nchunks, const hf_chunk_cb* __restrict__ cbs,
     const uint32_t* __restrict__ chunk_ids, const uint32_t* __restrict__ out_slots,
     const uint32_t n_slots, const uint32_t n_work, void* __restrict__ out, uint32_t* err) {
@@ -788,12 +789,18 @@ __global__ __launch_bounds__(kWavesC * 64) void hf_k_decode_chunks(
             continue;
         }
         const uint32_t off0 = __builtin_amdgcn_readfirstlane(chunk_off[c]);
-        const uint32_t off1 = __builtin_amdgcn_readfirstlane(chunk_off[c + 1]);
+        uint32_t off1 = __builtin_amdgcn_readfirstlane(chunk_off[c + 1]);
+        bool sane = off1 >= off0 && (uint64_t)off1 <= payload_words;
+        if (chunk_words) {
+            // a slotted stream: the chunk's words are the first chunk_words[c] of its slot
+            const uint32_t w = __builtin_amdgcn_readfirstlane(chunk_words[c]);
+            sane = sane && w <= off1 - off0;
+            off1 = off0 + w;
+        }
         const uint64_t first = (uint64_t)c * HF_CHUNK_SYMS;
         const uint64_t left = n - first;
         const uint32_t nvalid = left < HF_CHUNK_SYMS ? (uint32_t)left : HF_CHUNK_SYMS;
-        const bool sane = off1 >= off0 && (uint64_t)off1 <= payload_words &&
-                          (chunk_ids == nullptr || nvalid == HF_CHUNK_SYMS);
+        sane = sane && (chunk_ids == nullptr || nvalid == HF_CHUNK_SYMS);
         if (!sane) {
             if (lane == 0) atomicOr(err, HF_KERR_CORRUPT);
             continue;
@@ -830,7 +837,8 @@ __global__ __launch_bounds__(kWavesC * 64) void hf_k_decode_chunks(
 }  // namespace
 
 void hf_launch_decode_chunks(const uint32_t* d_payload, uint64_t payload_words,
-                             const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n,
+                             const uint32_t* d_chunk_off, const uint32_t* d_chunk_words,
+                             const uint8_t* d_side, uint64_t n,
                              int layout, const hf_chunk_cb* cbs, const uint32_t* d_chunk_ids,
                              const uint32_t* d_out_slots, uint64_t n_slots, uint64_t n_ids,
                              void* d_out, uint32_t* d_err, int num_cu, hipStream_t s) {
@@ -842,13 +850,14 @@ void hf_launch_decode_chunks(const uint32_t* d_payload, uint64_t payload_words,
     const uint64_t grid = (n_work + kWavesC - 1) / kWavesC;
     if (layout == HF_LAYOUT_BF16_EXP)
         hipLaunchKernelGGL(hf_k_decode_chunks<HF_LAYOUT_BF16_EXP>, dim3((unsigned)grid),
-                           dim3(kWavesC * 64), 0, s, d_payload, payload_words, d_chunk_off, d_side,
-                           n, (uint32_t)nchunks, cbs, d_chunk_ids, d_out_slots, (uint32_t)n_slots,
+                           dim3(kWavesC * 64), 0, s, d_payload, payload_words, d_chunk_off,
+                           d_chunk_words, d_side, n, (uint32_t)nchunks, cbs, d_chunk_ids, d_out_slots, (uint32_t)n_slots,
                            (uint32_t)n_work, d_out, d_err);
     else
         hipLaunchKernelGGL(hf_k_decode_chunks<HF_LAYOUT_U8>, dim3((unsigned)grid),
                            dim3(kWavesC * 64), 0, s, d_payload, payload_words, d_chunk_off,
-                           (const uint8_t*)nullptr, n, (uint32_t)nchunks, cbs, d_chunk_ids,
+                           d_chunk_words, (const uint8_t*)nullptr, n, (uint32_t)nchunks, cbs,
+                           d_chunk_ids,
                            d_out_slots, (uint32_t)n_slots, (uint32_t)n_work, d_out, d_err);
 }
 

@@ -600,7 +600,205 @@ hf_k_encode(const void* __restrict__ data, const uint64_t n, const uint32_t nchu
     }
 }
 
+// ---- slotted placement (per-block codebooks) ---------------------------------------------------
+// Every chunk's place is known before the encoder starts: chunk c owns a slot of
+// HF_SLOT_WORDS(B_c) = ceil(B_c / 32) + 126 words, B_c = sum over the chunk's symbols of their code
+// lengths, which the per-chunk histogram and the chunk's codebook give without reading the data
+// (a lane takes ceil(T / 32) + 1 words for T <= its own bits, and there are 64 lanes: no chunk
+// needs more).  Slot offsets are a prefix sum of the slot sizes.  With the place known, words go
+// straight to global memory as they complete: no staging in LDS, no tile descriptors, no look-back,
+// no scout, and a wavefront needs 1 KiB of LDS for its table instead of 17 KiB -- occupancy is
+// bounded by registers (6 workgroups of 4 wavefronts per CU) and the per-wavefront latency of
+// the symbol loop is covered by the other wavefronts.  What a slot has left over is zeroed.
+
+// slot size of every chunk into slot[c]; slot[nchunks] = 0 (the scan turns it into the total)
+__global__ __launch_bounds__(256) void hf_k_slot_sizes(const uint32_t* __restrict__ freq_chunks,
+                                                       const hf_chunk_cb* __restrict__ cbs,
+                                                       const uint32_t nchunks,
+                                                       uint32_t* __restrict__ slot) {
+    const int lane = hf_lane();
+    const uint32_t c = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (c > nchunks) return;
+    if (c == nchunks) {
+        if (lane == 0) slot[c] = 0;
+        return;
+    }
+    const uint4 f = reinterpret_cast<const uint4*>(freq_chunks + (size_t)c * 256)[lane];
+    const uint4 e = reinterpret_cast<const uint4*>(cbs[c].enc)[lane];
+    uint32_t bits = f.x * (e.x >> 16) + f.y * (e.y >> 16) + f.z * (e.z >> 16) + f.w * (e.w >> 16);
+    bits = hf_wave_sum_u32(bits);  // <= 16384 * 16
+    if (lane == 0) slot[c] = HF_SLOT_WORDS(bits);
+}
+
+// In-place exclusive prefix sum of m 32-bit values, three kernels: 1024 values per workgroup with
+// the workgroup's total set aside, the totals scanned by one workgroup, the totals added back.
+constexpr int kScanPerGroup = 1024;
+__global__ __launch_bounds__(256) void hf_k_scan_local(uint32_t* __restrict__ a, const uint64_t m,
+                                                       u64* __restrict__ group_sum) {
+    __shared__ uint32_t wave_tot[4];
+    const int lane = hf_lane(), wv = threadIdx.x >> 6;
+    const uint64_t i0 = (uint64_t)blockIdx.x * kScanPerGroup + threadIdx.x * 4u;
+    uint32_t v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = i0 + k < m ? a[i0 + k] : 0u;
+    const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    uint32_t base = incl - mine;
+    for (int w = 0; w < wv; ++w) base += wave_tot[w];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (i0 + k < m) a[i0 + k] = base;
+        base += v[k];
+    }
+    if (threadIdx.x == 255) group_sum[blockIdx.x] = (u64)base;  // (the group's total)
+}
+__global__ __launch_bounds__(256) void hf_k_scan_groups(u64* __restrict__ group_sum,
+                                                        const uint32_t ngroups) {
+    __shared__ u64 wave_tot[4];
+    __shared__ u64 carry_s;
+    const int lane = hf_lane(), wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t g0 = 0; g0 < ngroups; g0 += 256) {
+        const uint32_t g = g0 + threadIdx.x;
+        const u64 mine = g < ngroups ? group_sum[g] : 0ull;
+        u64 incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u64 t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wave_tot[wv] = incl;
+        __syncthreads();
+        u64 base = carry_s + incl - mine;
+        for (int w = 0; w < wv; ++w) base += wave_tot[w];
+        if (g < ngroups) group_sum[g] = base;
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = base + mine;
+        __syncthreads();
+    }
+}
+// (limit: what the last value -- the total -- may be at most; above it the stream does not fit the
+// payload buffer or its 32-bit offsets, and the encoder then leaves every chunk alone)
+__global__ __launch_bounds__(256) void hf_k_scan_add(uint32_t* __restrict__ a, const uint64_t m,
+                                                     const u64* __restrict__ group_sum,
+                                                     const u64 limit, uint32_t* err) {
+    const uint64_t i0 = (uint64_t)blockIdx.x * kScanPerGroup + threadIdx.x * 4u;
+    const u64 add = group_sum[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (i0 + k < m) {
+            const u64 v = (u64)a[i0 + k] + add;
+            a[i0 + k] = (uint32_t)v;
+            if (i0 + k == m - 1) {
+                err[1] = (uint32_t)v;  // the stream's words, where the host reads them
+                if (v > limit) atomicOr(err, HF_KERR_OVERFLOW);
+            }
+        }
+    }
+}
+
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void hf_k_encode_slotted(
+    const void* __restrict__ data, const uint64_t n, const uint32_t nchunks,
+    const hf_chunk_cb* __restrict__ cbs, uint8_t* __restrict__ side,
+    uint32_t* __restrict__ payload, const uint32_t* __restrict__ slot_off,
+    uint32_t* __restrict__ chunk_words, uint32_t* __restrict__ dump, uint32_t* err) {
+    __shared__ __attribute__((aligned(1024))) uint32_t enc_all[4 * 256];
+    const int lane = hf_lane();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // (an overflow found by the scan: the offsets mean nothing, nothing is written)
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & HF_KERR_OVERFLOW) return;
+    uint32_t* enc = enc_all + wave * 256;
+    const uint32_t enc_tab = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(enc));
+    const size_t elem_bytes = LAYOUT == HF_LAYOUT_BF16_EXP ? 2 : 1;
+    const uint32_t nwaves = gridDim.x * 4u;
+    for (uint32_t c = blockIdx.x * 4u + (uint32_t)wave; c < nchunks; c += nwaves) {
+        const uint64_t first = (uint64_t)c * HF_CHUNK_SYMS;
+        const uint64_t left = n - first;
+        const uint32_t nvalid = left < HF_CHUNK_SYMS ? (uint32_t)left : HF_CHUNK_SYMS;
+        const void* chunk_in = reinterpret_cast<const uint8_t*>(data) + first * elem_bytes;
+        uint8_t* side_chunk = side ? side + first : nullptr;
+        const uint32_t off0 = __builtin_amdgcn_readfirstlane(slot_off[c]);
+        const uint32_t slot = __builtin_amdgcn_readfirstlane(slot_off[c + 1]) - off0;
+        const hf_chunk_cb* ccb = cbs + c;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) enc[lane + 64 * k] = ccb->enc[lane + 64 * k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // The slot plays the staging area's part: words below its size land in it.  A word beyond
+        // it -- the counts were not this chunk's -- goes to a dump area of one chunk's maximum
+        // size that all wavefronts share (what it holds is never read), so nothing is written
+        // outside the slot, and the chunk is reported.
+        uint32_t* dst = payload + off0;
+        uint32_t total;
+        uint32_t buf[kDepth][4];
+        if (nvalid == HF_CHUNK_SYMS) {
+            preload_chunk<LAYOUT>(chunk_in, lane, buf);
+            total = encode_chunk<LAYOUT, true>(chunk_in, nvalid, enc_tab, dst, dump, slot,
+                                               side_chunk, lane, buf);
+        } else {
+            total = encode_chunk<LAYOUT, false>(chunk_in, nvalid, enc_tab, dst, dump, slot,
+                                                side_chunk, lane, buf);
+        }
+        total = __builtin_amdgcn_readfirstlane(total);
+        if (total > slot) {
+            if (lane == 0) atomicOr(err, HF_KERR_CORRUPT);
+            total = slot;
+        }
+        if (lane == 0) chunk_words[c] = total;
+        for (uint32_t k = total + (uint32_t)lane; k < slot; k += 64u) dst[k] = 0u;
+        // the table is rewritten for the next chunk: all lookups of this one are done
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace
+
+size_t hf_scan_aux_bytes(uint64_t m) {
+    return (size_t)((m + kScanPerGroup - 1) / kScanPerGroup) * sizeof(u64);
+}
+
+// slot sizes -> slot offsets (in d_slot_off, nchunks + 1 values) -> chunks encoded in their slots
+void hf_launch_encode_chunks_slotted(const void* d_data, uint64_t n, int layout,
+                                     const hf_chunk_cb* cbs, const uint32_t* d_freq_chunks,
+                                     uint8_t* d_side, uint32_t* d_payload, uint64_t cap_words,
+                                     uint32_t* d_slot_off, uint32_t* d_chunk_words,
+                                     unsigned long long* d_scan_aux, uint32_t* d_dump,
+                                     uint32_t* d_err, int num_cu, hipStream_t s) {
+    static_assert(2 * kSpillWords >= kMaxChunkWords, "the dump area is the v1 encoder's spill area");
+    const uint64_t nchunks = (n + HF_CHUNK_SYMS - 1) / HF_CHUNK_SYMS;
+    if (nchunks == 0) return;
+    const uint64_t m = nchunks + 1;
+    const unsigned ngroups = (unsigned)((m + kScanPerGroup - 1) / kScanPerGroup);
+    hipLaunchKernelGGL(hf_k_slot_sizes, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, s, d_freq_chunks,
+                       cbs, (uint32_t)nchunks, d_slot_off);
+    hipLaunchKernelGGL(hf_k_scan_local, dim3(ngroups), dim3(256), 0, s, d_slot_off, m, d_scan_aux);
+    hipLaunchKernelGGL(hf_k_scan_groups, dim3(1), dim3(256), 0, s, d_scan_aux, ngroups);
+    const u64 limit = cap_words < 0xFFFFFFFFull ? cap_words : 0xFFFFFFFFull;
+    hipLaunchKernelGGL(hf_k_scan_add, dim3(ngroups), dim3(256), 0, s, d_slot_off, m, d_scan_aux, limit,
+                       d_err);
+    uint64_t grid = (nchunks + 3) / 4;
+    const uint64_t cap = (uint64_t)num_cu * 6;
+    if (grid > cap) grid = cap;
+    if (layout == HF_LAYOUT_BF16_EXP)
+        hipLaunchKernelGGL(hf_k_encode_slotted<HF_LAYOUT_BF16_EXP>, dim3((unsigned)grid), dim3(256),
+                           0, s, d_data, n, (uint32_t)nchunks, cbs, d_side, d_payload, d_slot_off,
+                           d_chunk_words, d_dump, d_err);
+    else
+        hipLaunchKernelGGL(hf_k_encode_slotted<HF_LAYOUT_U8>, dim3((unsigned)grid), dim3(256), 0, s,
+                           d_data, n, (uint32_t)nchunks, cbs, (uint8_t*)nullptr, d_payload,
+                           d_slot_off, d_chunk_words, d_dump, d_err);
+}
 
 size_t hf_encode_spill_bytes(int num_cu) {
     return (size_t)num_cu * 2 * kWaves * 2 * kSpillWords * sizeof(uint32_t);

@@ -219,6 +219,8 @@ int hf_encode(hf_ctx* ctx, const void* d_data, uint64_t n, int layout, const voi
               uint8_t* d_side, uint32_t* d_payload, uint64_t payload_cap_words,
               uint32_t* d_chunk_off, uint64_t* h_total_words);
 uint64_t hf_num_chunks(uint64_t n);
+/* words of a chunk's slot in a slotted stream (hf_encode_chunks_slotted), from the bits of its codes */
+#define HF_SLOT_WORDS(bits) (((bits) + 31u) / 32u + 126u)
 /* worst case over all codebooks with lengths <= 16 */
 uint64_t hf_payload_bound_words(uint64_t n);
 
@@ -279,6 +281,35 @@ int hf_decode_chunks_to(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload
                         const void* d_chunk_codebooks, const uint32_t* d_chunk_ids,
                         const uint32_t* d_out_slots, uint64_t n_ids, void* d_out, uint64_t n_slots,
                         int check);
+/* Slotted placement of a per-block stream.  Chunk c is encoded with its own codebook exactly as by
+ * hf_encode_chunks -- the same words in the same order -- but its place is fixed before the
+ * encoder runs: it owns a slot of HF_SLOT_WORDS(B_c) words, B_c = the bits of its codes (from
+ * d_freq_chunks, the histograms the codebooks were built from, and the codebooks' lengths), which
+ * no chunk can outgrow.  d_chunk_off[c] = start of slot c (prefix sum of the slot sizes,
+ * nchunks + 1 values, the last one the stream's words), d_chunk_words[c] = words the chunk filled;
+ * the rest of a slot is zero.  The stream is 2-4 % larger than the dense one (about 54 words per
+ * full chunk) and is written without staging or look-back, at 1.0-1.7x the dense encoder's rate.
+ * It is not a format-v1 payload: hf_container_pack does not take it, and it is decoded by
+ * hf_decode_chunks_slotted only.  payload_cap_words >= hf_slotted_bound_words(n) always fits; a
+ * smaller buffer that the slots do not fit gives HF_ERR_OVERFLOW and nothing is written.
+ * Histograms that are not this data's give HF_ERR_CORRUPT (a chunk outgrew its slot; nothing is
+ * written outside the slot).  No counterpart in the reference (its top level stops at the
+ * codebook, top.scala:60-67); meant for KV-cache pages, where encode rate matters more than the
+ * last 3 % of ratio. */
+uint64_t hf_slotted_bound_words(uint64_t n);
+int hf_encode_chunks_slotted(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
+                             const void* d_chunk_codebooks, const uint32_t* d_freq_chunks,
+                             uint8_t* d_side, uint32_t* d_payload, uint64_t payload_cap_words,
+                             uint32_t* d_chunk_off, uint32_t* d_chunk_words,
+                             uint64_t* h_total_words);
+/* decodes a slotted stream: all chunks (d_chunk_ids NULL), listed chunks to consecutive pages
+ * (d_out_slots NULL), or listed chunks to named pages -- as hf_decode_chunks / hf_decode_chunks_to */
+int hf_decode_chunks_slotted(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
+                             const uint32_t* d_chunk_off, const uint32_t* d_chunk_words,
+                             const uint8_t* d_side, uint64_t n, int layout,
+                             const void* d_chunk_codebooks, const uint32_t* d_chunk_ids,
+                             const uint32_t* d_out_slots, uint64_t n_ids, void* d_out,
+                             uint64_t n_slots, int check);
 /* bulk read of one record: code/length by symbol, mode, entropy (synchronises) */
 int hf_chunk_codebook_download(hf_ctx* ctx, const void* d_chunk_codebooks, uint64_t chunk,
                                uint16_t* h_code, uint8_t* h_len, int* mode, uint32_t* entropy_q16);

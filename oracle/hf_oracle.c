@@ -802,6 +802,30 @@ uint64_t orc_rp_encode_blocks(const uint8_t* sym, size_t n, uint64_t min_freq_th
     return pos;
 }
 
+uint64_t orc_rp_slot_blocks(const uint8_t* sym, size_t n, const uint8_t* len,
+                            const uint32_t* payload, const uint32_t* chunk_off,
+                            uint32_t* slot_payload, uint32_t* slot_off, uint32_t* words) {
+    const size_t nchunks = (n + ORC_CHUNK_SYMS - 1) / ORC_CHUNK_SYMS;
+    uint64_t at = 0;
+    for (size_t c = 0; c < nchunks; ++c) {
+        const size_t first = c * ORC_CHUNK_SYMS;
+        const size_t m = n - first < ORC_CHUNK_SYMS ? n - first : ORC_CHUNK_SYMS;
+        uint64_t bits = 0;
+        for (size_t i = 0; i < m; ++i) bits += len[c * 256 + sym[first + i]];
+        const uint64_t slot = ORC_SLOT_WORDS(bits);
+        const uint32_t w = chunk_off[c + 1] - chunk_off[c];
+        slot_off[c] = (uint32_t)at;
+        words[c] = w;
+        if (slot_payload) {
+            memcpy(slot_payload + at, payload + chunk_off[c], 4u * (size_t)w);
+            memset(slot_payload + at + w, 0, 4u * (size_t)(slot - w));
+        }
+        at += slot;
+    }
+    slot_off[nchunks] = (uint32_t)at;
+    return at;
+}
+
 int orc_rp_decode_blocks(const uint32_t* payload, const uint32_t* chunk_off, size_t n,
                          const uint16_t* code, const uint8_t* len, uint8_t* sym_out) {
     const size_t nchunks = orc_num_chunks(n);

@@ -168,6 +168,19 @@ int orc_rp_decode(const uint32_t* payload, const uint32_t* chunk_off, size_t n,
 uint64_t orc_rp_encode_blocks(const uint8_t* sym, size_t n, uint64_t min_freq_threshold,
                               uint16_t* code, uint8_t* len, uint32_t* payload,
                               uint32_t* chunk_off);
+/* Slotted placement of a per-block stream (an alternative to the back-to-back one above, for
+ * encoders that want every chunk's place before they start): chunk c gets a slot of
+ * ORC_SLOT_WORDS(B_c) = ceil(B_c / 32) + 126 words, B_c = the bits of the chunk's codes
+ * (sum over its symbols of len[c][symbol]) -- no chunk needs more: a lane takes
+ * ceil(T / 32) + 1 words for T <= its own bits, and there are 64 lanes.  The chunk's words are the
+ * same words in the same order; slot_off[c] = sum of the earlier slots, slot_off[nchunks] = their
+ * total, words[c] = the words the chunk really has, and the rest of each slot is zero.
+ * `payload` / `chunk_off`: the back-to-back stream of orc_rp_encode_blocks.  Returns the total
+ * slot words (slot_payload may be NULL to size only). */
+#define ORC_SLOT_WORDS(bits) (((bits) + 31u) / 32u + 126u)
+uint64_t orc_rp_slot_blocks(const uint8_t* sym, size_t n, const uint8_t* len,
+                            const uint32_t* payload, const uint32_t* chunk_off,
+                            uint32_t* slot_payload, uint32_t* slot_off, uint32_t* words);
 int orc_rp_decode_blocks(const uint32_t* payload, const uint32_t* chunk_off, size_t n,
                          const uint16_t* code, const uint8_t* len, uint8_t* sym_out);
 

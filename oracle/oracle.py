@@ -416,6 +416,25 @@ def rp_encode_blocks(sym, thr: int = 0, payload_words: int = 0):
     return payload[:total], off, code[:nch], lens[:nch]
 
 
+def rp_encode_blocks_slotted(sym, thr: int = 0):
+    """The per-block stream with every chunk in a slot of ceil(bits / 32) + 126 words:
+    (payload u32, slot_off u32[nchunks+1], words u32[nchunks], code, len)."""
+    sym = _arr(sym, np.uint8)
+    payload, off, code, lens = rp_encode_blocks(sym, thr)
+    nch = num_chunks(sym.size)
+    slot_off = np.zeros(nch + 1, np.uint32)
+    words = np.zeros(max(nch, 1), np.uint32)
+    lens_c = _arr(lens if nch else np.zeros((1, 256), np.uint8), np.uint8)
+    pay = payload if payload.size else np.zeros(1, np.uint32)
+    total = int(lib().orc_rp_slot_blocks(_p(sym, _u8p), sym.size, _p(lens_c, _u8p), _p(pay, _u32p),
+                                         _p(off, _u32p), None, _p(slot_off, _u32p),
+                                         _p(words, _u32p)))
+    out = np.zeros(max(total, 1), np.uint32)
+    lib().orc_rp_slot_blocks(_p(sym, _u8p), sym.size, _p(lens_c, _u8p), _p(pay, _u32p),
+                             _p(off, _u32p), _p(out, _u32p), _p(slot_off, _u32p), _p(words, _u32p))
+    return out[:total], slot_off, words[:nch], code, lens
+
+
 def rp_decode_blocks(payload, chunk_off, n: int, code, lens) -> np.ndarray:
     payload = _arr(payload, np.uint32)
     if payload.size == 0:

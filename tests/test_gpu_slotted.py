@@ -1,0 +1,176 @@
+"""Slotted placement of a per-block stream (hf_encode_chunks_slotted / hf_decode_chunks_slotted)
+against the oracle's restatement: slot offsets, words per chunk, every payload word including the
+zeroed slot tails, round trips, decode-on-read and the refusals.  The reference has no packer
+(top.scala:60-67 stops at the codebook); the chunk words are those of the dense per-block stream."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def to_dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def make(kind, n, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "geom":
+        return np.minimum(rng.geometric(0.08, n) - 1, 255).astype(np.uint8)
+    if kind == "uniform":
+        return rng.integers(0, 256, n).astype(np.uint8)
+    if kind == "const":
+        return np.full(n, 7, np.uint8)
+    if kind == "mixed":  # another distribution in every chunk
+        out = np.empty(n, np.uint8)
+        for c in range(0, n, 16384):
+            m = min(16384, n - c)
+            p = [0.5, 0.08, 0.02, 0.9][(c // 16384) % 4]
+            out[c:c + m] = np.minimum(rng.geometric(p, m) - 1, 255) + (c // 16384) * 3 % 200
+        return out
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind,n", [
+    ("geom", 1), ("geom", 511), ("geom", 16384), ("geom", 16385), ("mixed", 9 * 16384 + 77),
+    ("uniform", 4 * 16384), ("const", 3 * 16384 + 5), ("mixed", 1100 * 16384 + 4097),
+])
+def test_slotted_stream_matches_the_oracle(hf, orc, kind, n):
+    sym = make(kind, n, n % 1000 + 5)
+    t = to_dev(sym)
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    dec = hf.ParrallelHuffmanDecoder(ctx=sys_.ctx)
+    s = sys_.encode_blocks(t, mode=hf.HF_MODE_HUFFMAN, slotted=True)
+    payload, slot_off, words, code, lens = orc.rp_encode_blocks_slotted(sym)
+    nch = s.nchunks
+    assert s.total_words == payload.size == int(slot_off[nch])
+    assert np.array_equal(s.chunk_off[: nch + 1].cpu().numpy().view(np.uint32), slot_off)
+    assert np.array_equal(s.chunk_words[:nch].cpu().numpy().view(np.uint32), words)
+    assert np.array_equal(s.payload[: payload.size].cpu().numpy().view(np.uint32), payload)
+    # the chunks' words are the dense per-block stream's
+    dense = sys_.encode_blocks(t, mode=hf.HF_MODE_HUFFMAN)
+    d_off = dense.chunk_off[: nch + 1].cpu().numpy().view(np.uint32)
+    assert np.array_equal(np.diff(d_off.astype(np.int64)), words.astype(np.int64))
+    dp = dense.payload.cpu().numpy().view(np.uint32)
+    sp = s.payload.cpu().numpy().view(np.uint32)
+    for c in {0, nch // 2, nch - 1}:
+        assert np.array_equal(sp[slot_off[c]: slot_off[c] + words[c]], dp[d_off[c]: d_off[c + 1]])
+    assert torch.equal(dec.decode(s), t)
+    with pytest.raises(ValueError):
+        s.to_container()
+
+
+def test_slotted_bf16_blocks_round_trip(hf, orc):
+    n = 37 * 16384 + 1234
+    rng = np.random.default_rng(3)
+    w = (rng.standard_normal(n) * 0.02).astype(np.float32)
+    bits = (w.view(np.uint32) >> 16).astype(np.uint16)
+    t = to_dev(bits).view(torch.bfloat16)
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    dec = hf.ParrallelHuffmanDecoder(ctx=sys_.ctx)
+    s = sys_.encode_blocks(t, mode=hf.HF_MODE_HUFFMAN, slotted=True)
+    esym, eside = orc.symbolize(bits, orc.LAYOUT_BF16_EXP)
+    payload, slot_off, words, _, _ = orc.rp_encode_blocks_slotted(esym)
+    assert s.total_words == payload.size
+    assert np.array_equal(s.payload[: payload.size].cpu().numpy().view(np.uint32), payload)
+    assert np.array_equal(s.side[:n].cpu().numpy(), eside)
+    assert np.array_equal(s.chunk_words[: s.nchunks].cpu().numpy().view(np.uint32), words)
+    out = dec.decode(s)
+    assert torch.equal(out.view(torch.int16), t.view(torch.int16))
+
+
+def test_slotted_sub_field_layout_round_trip(hf, orc):
+    n = 11 * 16384 + 9
+    rng = np.random.default_rng(9)
+    w = (rng.standard_normal(n) * 0.05).astype(np.float16)
+    t = to_dev(w)
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    dec = hf.ParrallelHuffmanDecoder(ctx=sys_.ctx)
+    s = sys_.encode_blocks(t, mode=hf.HF_MODE_HUFFMAN, layout=hf.HF_LAYOUT_FP16_EXP, slotted=True)
+    esym, eside = orc.symbolize(w.view(np.uint16), orc.LAYOUT_FP16_EXP)
+    payload, _, _, _, _ = orc.rp_encode_blocks_slotted(esym)
+    assert np.array_equal(s.payload[: payload.size].cpu().numpy().view(np.uint32), payload)
+    assert np.array_equal(s.side.cpu().numpy(), eside)
+    assert torch.equal(dec.decode(s).view(torch.int16), t.view(torch.int16))
+
+
+def test_slotted_decode_on_read_and_paged(hf, orc):
+    pages = 40
+    n = pages * 16384
+    sym = make("mixed", n, 17)
+    t = to_dev(sym)
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    dec = hf.ParrallelHuffmanDecoder(ctx=sys_.ctx)
+    s = sys_.encode_blocks(t, slotted=True)  # AUTO: some blocks may be bypassed
+    ids = np.array([39, 0, 17, 17, 5], np.int32)
+    got = dec.decode_blocks(s, to_dev(ids))
+    want = np.concatenate([sym[i * 16384:(i + 1) * 16384] for i in ids])
+    assert np.array_equal(got.cpu().numpy(), want)
+    pool = torch.zeros(8 * 16384, dtype=torch.uint8, device=DEV)
+    slots = np.array([7, 2, 0, 4, 5], np.int32)
+    dec.decode_blocks_to(s, to_dev(ids), to_dev(slots), pool)
+    p = pool.cpu().numpy()
+    for i, sl in zip(ids, slots):
+        assert np.array_equal(p[sl * 16384:(sl + 1) * 16384], sym[i * 16384:(i + 1) * 16384])
+    assert not p[16384: 2 * 16384].any()
+    assert torch.equal(dec.decode(s), t)
+
+
+def test_slotted_refusals(hf, orc):
+    n = 6 * 16384
+    sym = make("geom", n, 23)
+    t = to_dev(sym)
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    ctx = sys_.ctx
+    lib, h = hf.L.lib(), ctx.handle
+    s = sys_.encode_blocks(t, mode=hf.HF_MODE_HUFFMAN, slotted=True)
+    P = lambda x: C.c_void_p(x.data_ptr())
+    total = C.c_uint64(0)
+    # a payload buffer the slots do not fit: reported, nothing written
+    small = torch.full((s.total_words - 1,), 0x5A5A5A5A, dtype=torch.int32, device=DEV)
+    off = torch.empty(8, dtype=torch.int32, device=DEV)
+    cw = torch.empty(8, dtype=torch.int32, device=DEV)
+    rc = lib.hf_encode_chunks_slotted(h, P(t), n, 0, P(s.chunk_codebooks), P(s.chunk_freq), None,
+                                      P(small), small.numel(), P(off), P(cw), C.byref(total))
+    assert rc == hf.L.HF_ERR_OVERFLOW
+    assert bool((small == 0x5A5A5A5A).all())
+    # histograms of other data: a chunk outgrows its slot, nothing lands outside the slots
+    rare = int(np.bincount(sym, minlength=256).argmin())
+    other = to_dev(np.full(n, rare, np.uint8))
+    cap = s.total_words
+    guard = 4096
+    buf = torch.full((cap + guard,), 0x5A5A5A5A, dtype=torch.int32, device=DEV)
+    rc = lib.hf_encode_chunks_slotted(h, P(other), n, 0, P(s.chunk_codebooks), P(s.chunk_freq),
+                                      None, P(buf), cap, P(off), P(cw), C.byref(total))
+    code, lens, _, _ = sys_.block_codebook(s, 0)
+    if int(lens[rare]) * 16384 > int(s.chunk_words[0].item()) * 32 + 126 * 32:
+        assert rc == hf.L.HF_ERR_CORRUPT
+    assert bool((buf[cap:] == 0x5A5A5A5A).all())
+    # a stream without its words array, a chunk whose words pass its slot
+    out = torch.empty(n, dtype=torch.uint8, device=DEV)
+    rc = lib.hf_decode_chunks_slotted(h, P(s.payload), s.payload.numel(), P(s.chunk_off), None,
+                                      None, n, 0, P(s.chunk_codebooks), None, None, 0, P(out), 0, 1)
+    assert rc == hf.L.HF_ERR_ARG
+    bad = s.chunk_words.clone()
+    bad[2] = int(s.chunk_off[3].item()) - int(s.chunk_off[2].item()) + 1
+    rc = lib.hf_decode_chunks_slotted(h, P(s.payload), s.payload.numel(), P(s.chunk_off), P(bad),
+                                      None, n, 0, P(s.chunk_codebooks), None, None, 0, P(out), 0, 1)
+    assert rc == hf.L.HF_ERR_CORRUPT
+    got = out.cpu().numpy()
+    assert np.array_equal(got[: 2 * 16384], sym[: 2 * 16384])
+    assert np.array_equal(got[3 * 16384:], sym[3 * 16384:])
+    # the context is usable afterwards
+    s2 = sys_.encode_blocks(t, mode=hf.HF_MODE_HUFFMAN, slotted=True)
+    assert s2.total_words == s.total_words
+
+
+def test_slotted_empty_input(hf, orc):
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    dec = hf.ParrallelHuffmanDecoder(ctx=sys_.ctx)
+    t = torch.empty(0, dtype=torch.uint8, device=DEV)
+    s = sys_.encode_blocks(t, slotted=True)
+    assert s.total_words == 0 and int(s.chunk_off[0].item()) == 0
+    assert dec.decode(s).numel() == 0

@@ -47,8 +47,14 @@ def main():
     ids = torch.randperm(nch, device=dev)[:a.read_batch].to(torch.int32)
     out2 = torch.empty(ids.numel() * CH, dtype=torch.uint8, device=dev)
     P = lambda x: C.c_void_p(x.data_ptr())
-    tm = {k: [] for k in ("hist", "codebook", "encode", "decode", "read")}
-    total = C.c_uint64(0)
+    tm = {k: [] for k in ("hist", "codebook", "encode", "decode", "read", "encode_slot",
+                          "decode_slot", "read_slot")}
+    total, total_s = C.c_uint64(0), C.c_uint64(0)
+    payload_s = torch.empty(nch * L.HF_SLOT_WORDS(CH * 8), dtype=torch.int32, device=dev)
+    off_s = torch.empty(nch + 4, dtype=torch.int32, device=dev)
+    words_s = torch.empty(nch + 4, dtype=torch.int32, device=dev)
+    out_s = torch.empty(n, dtype=torch.uint8, device=dev)
+    out2_s = torch.empty(ids.numel() * CH, dtype=torch.uint8, device=dev)
     for _ in range(a.reps):
         L.check(lib.hf_symbol_stat_chunks_dev(h, P(t), n, 0, P(freq)), "stat")
         tm["hist"].append(ctx.last_kernel_ms())
@@ -67,14 +73,32 @@ def main():
         if not a.no_check:
             L.check(rc, "read")
         tm["read"].append(ctx.last_kernel_ms())
+        # the same pages in slots sized from their histograms
+        L.check(lib.hf_encode_chunks_slotted(h, P(t), n, 0, P(cbs), P(freq), None, P(payload_s),
+                                             payload_s.numel(), P(off_s), P(words_s),
+                                             C.byref(total_s)), "encode_slotted")
+        tm["encode_slot"].append(ctx.last_kernel_ms())
+        L.check(lib.hf_decode_chunks_slotted(h, P(payload_s), payload_s.numel(), P(off_s),
+                                             P(words_s), None, n, 0, P(cbs), None, None, 0,
+                                             P(out_s), 0, 1), "decode_slotted")
+        tm["decode_slot"].append(ctx.last_kernel_ms())
+        L.check(lib.hf_decode_chunks_slotted(h, P(payload_s), payload_s.numel(), P(off_s),
+                                             P(words_s), None, n, 0, P(cbs), P(ids), None,
+                                             ids.numel(), P(out2_s), 0, 1), "read_slotted")
+        tm["read_slot"].append(ctx.last_kernel_ms())
     ok = torch.equal(out, t) and torch.equal(out2, t.view(nch, CH)[ids.long()].reshape(-1))
+    ok_s = torch.equal(out_s, t) and torch.equal(out2_s, out2)
     gb = n / 1e9
     bits = 32.0 * total.value / n
     comp = 4 * total.value + 4 * (nch + 1) + 273 * nch
     print(f"pages={nch} ({gb:.2f} GB) bits/sym={bits:.3f} ratio={n / comp:.3f} ok={ok}")
+    comp_s = 4 * total_s.value + 4 * (2 * nch + 1) + 273 * nch
+    print(f"slotted: words {total_s.value} (+{100.0 * (total_s.value / total.value - 1):.2f} %) "
+          f"ratio={n / comp_s:.3f} ok={ok_s}")
     for k, v in tm.items():
-        b = gb if k != "read" else ids.numel() * CH / 1e9
-        per = min(v) * 1e3 / (nch if k != "read" else ids.numel())
+        rd = k.startswith("read")
+        b = gb if not rd else ids.numel() * CH / 1e9
+        per = min(v) * 1e3 / (nch if not rd else ids.numel())
         print(f"  {k:9s} {min(v):8.3f} ms  {b / (min(v) * 1e-3):8.0f} GB/s  {per:7.3f} us/page-slot")
 
 
