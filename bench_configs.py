@@ -323,6 +323,56 @@ def config3(args):
         "library_sha256_16": bench.library_hash(),
         "roofline": dict(roof[dominant], kernel=dominant), "roofline_all": roof,
     }
+    # The same pages in slots sized from their histograms (hf_encode_chunks_slotted): timed beside
+    # the step above, never part of `value`.
+    payload_s = torch.empty(pages * L.HF_SLOT_WORDS(CH * 8), dtype=torch.int32, device=dev)
+    off_s = torch.empty(pages + 4, dtype=torch.int32, device=dev)
+    words_s = torch.empty(pages + 4, dtype=torch.int32, device=dev)
+    out.zero_()
+    pool.zero_()
+
+    def step_slotted(ev=None):
+        if ev: ev[0].record()
+        L.check(lib.hf_encode_chunks_slotted(h, P(t), n, 0, P(cbs), P(freq), None, P(payload_s),
+                                             payload_s.numel(), P(off_s), P(words_s), None),
+                "encode_slotted")
+        if ev: ev[1].record()
+        L.check(lib.hf_decode_chunks_slotted(h, P(payload_s), payload_s.numel(), P(off_s),
+                                             P(words_s), None, n, 0, P(cbs), None, None, 0, P(out),
+                                             0, 0), "decode_slotted")
+        if ev: ev[2].record()
+        L.check(lib.hf_decode_chunks_slotted(h, P(payload_s), payload_s.numel(), P(off_s),
+                                             P(words_s), None, n, 0, P(cbs), P(ids), P(slots),
+                                             n_read, P(pool), n_read, 0), "read_slotted")
+        if ev: ev[3].record()
+
+    for _ in range(args.warmup):
+        step_slotted()
+    torch.cuda.synchronize()
+    evs = [_events(torch, 4) for _ in range(args.steps)]
+    for k in range(args.steps):
+        step_slotted(evs[k])
+    torch.cuda.synchronize()
+    ctx.sync()
+    ms_s = _phase_ms(evs, ["encode", "decode", "decode_on_read"])
+    words_slotted = int(off_s[pages].item()) & 0xFFFFFFFF
+    ok_s = bool(torch.equal(out, t)) and bool(torch.equal(pool.view(n_read, CH)[slots.long()],
+                                                          t.view(pages, CH)[ids.long()]))
+    ok_s = ok_s and int(words_s[:pages].sum().item()) == total_words
+    ok = ok and ok_s
+    comp_s = 4 * words_slotted + 4 * (2 * pages + 1) + L.HF_CONTAINER_CHUNK_CODEBOOK_BYTES * pages
+    # (per page: 1 KiB of counts and 1 KiB of code lengths read for the slot size, two 4-byte
+    # index entries written; the payload bytes written are the slots, tails included)
+    alg_s = n + 4.0 * words_slotted + (2048.0 + 8.0) * pages
+    line["slotted"] = {
+        "encode_kernel_GBps": n / (ms_s["encode"] * 1e-3) / 1e9,
+        "encode_GBps": n / ((ms["hist"] + ms["codebook"] + ms_s["encode"]) * 1e-3) / 1e9,
+        "decode_GBps": n / (ms_s["decode"] * 1e-3) / 1e9,
+        "decode_on_read_us": ms_s["decode_on_read"] * 1e3,
+        "payload_words_over_dense": words_slotted / total_words,
+        "compression_ratio": n / comp_s, "roundtrip_bit_exact": ok_s,
+        "roofline_encode": _roof(alg_s, ms_s["encode"]),
+    }
     if not args.no_cpu_baseline:
         m = min(pages, 49152) * CH  # 0.8 GB: about 15 s of one core
         sy = t[:m].cpu().numpy()

@@ -608,8 +608,8 @@ hf_k_encode(const void* __restrict__ data, const uint64_t n, const uint32_t nchu
 // needs more).  Slot offsets are a prefix sum of the slot sizes.  With the place known, words go
 // straight to global memory as they complete: no staging in LDS, no tile descriptors, no look-back,
 // no scout, and a wavefront needs 1 KiB of LDS for its table instead of 17 KiB -- occupancy is
-// bounded by registers (6 workgroups of 4 wavefronts per CU) and the per-wavefront latency of
-// the symbol loop is covered by the other wavefronts.  What a slot has left over is zeroed.
+// bounded by registers, not LDS, and the per-wavefront latency of the symbol loop is covered by
+// the other wavefronts.  What a slot has left over is zeroed.
 
 // slot size of every chunk into slot[c]; slot[nchunks] = 0 (the scan turns it into the total)
 __global__ __launch_bounds__(256) void hf_k_slot_sizes(const uint32_t* __restrict__ freq_chunks,
@@ -788,7 +788,9 @@ void hf_launch_encode_chunks_slotted(const void* d_data, uint64_t n, int layout,
     hipLaunchKernelGGL(hf_k_scan_add, dim3(ngroups), dim3(256), 0, s, d_slot_off, m, d_scan_aux, limit,
                        d_err);
     uint64_t grid = (nchunks + 3) / 4;
-    const uint64_t cap = (uint64_t)num_cu * 6;
+    // (measured flat from 4 to 8 workgroups per CU, 7 a hair ahead; 65 registers allow 7
+    // wavefronts per SIMD on byte symbols, 108 allow 4 on 16-bit elements)
+    const uint64_t cap = (uint64_t)num_cu * 7;
     if (grid > cap) grid = cap;
     if (layout == HF_LAYOUT_BF16_EXP)
         hipLaunchKernelGGL(hf_k_encode_slotted<HF_LAYOUT_BF16_EXP>, dim3((unsigned)grid), dim3(256),
