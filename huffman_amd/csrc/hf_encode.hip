@@ -686,9 +686,10 @@ __global__ __launch_bounds__(256) void hf_k_scan_groups(u64* __restrict__ group_
     }
 }
 // (limit: what the last value -- the total -- may be at most; above it the stream does not fit the
-// payload buffer or its 32-bit offsets, and the encoder then leaves every chunk alone)
+// payload buffer or its 32-bit offsets.  The total goes to group_sum[number of groups] in 64 bits:
+// the encoder compares it with the limit itself and then leaves every chunk alone.)
 __global__ __launch_bounds__(256) void hf_k_scan_add(uint32_t* __restrict__ a, const uint64_t m,
-                                                     const u64* __restrict__ group_sum,
+                                                     u64* __restrict__ group_sum,
                                                      const u64 limit, uint32_t* err) {
     const uint64_t i0 = (uint64_t)blockIdx.x * kScanPerGroup + threadIdx.x * 4u;
     const u64 add = group_sum[blockIdx.x];
@@ -698,6 +699,7 @@ __global__ __launch_bounds__(256) void hf_k_scan_add(uint32_t* __restrict__ a, c
             const u64 v = (u64)a[i0 + k] + add;
             a[i0 + k] = (uint32_t)v;
             if (i0 + k == m - 1) {
+                group_sum[gridDim.x] = v;
                 err[1] = (uint32_t)v;  // the stream's words, where the host reads them
                 if (v > limit) atomicOr(err, HF_KERR_OVERFLOW);
             }
@@ -710,12 +712,14 @@ __global__ __launch_bounds__(256) void hf_k_encode_slotted(
     const void* __restrict__ data, const uint64_t n, const uint32_t nchunks,
     const hf_chunk_cb* __restrict__ cbs, uint8_t* __restrict__ side,
     uint32_t* __restrict__ payload, const uint32_t* __restrict__ slot_off,
-    uint32_t* __restrict__ chunk_words, uint32_t* __restrict__ dump, uint32_t* err) {
+    uint32_t* __restrict__ chunk_words, uint32_t* __restrict__ dump,
+    const u64* __restrict__ total_words, const u64 limit, uint32_t* err) {
     __shared__ __attribute__((aligned(1024))) uint32_t enc_all[4 * 256];
     const int lane = hf_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // (an overflow found by the scan: the offsets mean nothing, nothing is written)
-    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & HF_KERR_OVERFLOW) return;
+    // (the slots do not fit, which the scan has reported: the offsets mean nothing, nothing is
+    // written)
+    if (*total_words > limit) return;
     uint32_t* enc = enc_all + wave * 256;
     const uint32_t enc_tab = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(enc));
     const size_t elem_bytes = LAYOUT == HF_LAYOUT_BF16_EXP ? 2 : 1;
@@ -765,7 +769,8 @@ __global__ __launch_bounds__(256) void hf_k_encode_slotted(
 }  // namespace
 
 size_t hf_scan_aux_bytes(uint64_t m) {
-    return (size_t)((m + kScanPerGroup - 1) / kScanPerGroup) * sizeof(u64);
+    // (one total per group of the scan, and the grand total behind them)
+    return (size_t)((m + kScanPerGroup - 1) / kScanPerGroup + 1) * sizeof(u64);
 }
 
 // slot sizes -> slot offsets (in d_slot_off, nchunks + 1 values) -> chunks encoded in their slots
@@ -787,6 +792,7 @@ void hf_launch_encode_chunks_slotted(const void* d_data, uint64_t n, int layout,
     const u64 limit = cap_words < 0xFFFFFFFFull ? cap_words : 0xFFFFFFFFull;
     hipLaunchKernelGGL(hf_k_scan_add, dim3(ngroups), dim3(256), 0, s, d_slot_off, m, d_scan_aux, limit,
                        d_err);
+    const u64* d_total = d_scan_aux + ngroups;
     uint64_t grid = (nchunks + 3) / 4;
     // (measured flat from 4 to 8 workgroups per CU, 7 a hair ahead; 65 registers allow 7
     // wavefronts per SIMD on byte symbols, 108 allow 4 on 16-bit elements)
@@ -795,11 +801,11 @@ void hf_launch_encode_chunks_slotted(const void* d_data, uint64_t n, int layout,
     if (layout == HF_LAYOUT_BF16_EXP)
         hipLaunchKernelGGL(hf_k_encode_slotted<HF_LAYOUT_BF16_EXP>, dim3((unsigned)grid), dim3(256),
                            0, s, d_data, n, (uint32_t)nchunks, cbs, d_side, d_payload, d_slot_off,
-                           d_chunk_words, d_dump, d_err);
+                           d_chunk_words, d_dump, d_total, limit, d_err);
     else
         hipLaunchKernelGGL(hf_k_encode_slotted<HF_LAYOUT_U8>, dim3((unsigned)grid), dim3(256), 0, s,
                            d_data, n, (uint32_t)nchunks, cbs, (uint8_t*)nullptr, d_payload,
-                           d_slot_off, d_chunk_words, d_dump, d_err);
+                           d_slot_off, d_chunk_words, d_dump, d_total, limit, d_err);
 }
 
 size_t hf_encode_spill_bytes(int num_cu) {

@@ -57,7 +57,8 @@ def test_block_pipeline_replays_from_a_captured_graph(hf, orc, n):
         assert np.array_equal(off[: nch + 1].cpu().numpy().view(np.uint32), ref_off)
 
 
-def test_per_block_pipeline_replays_from_a_captured_graph(hf, orc):
+@pytest.mark.parametrize("slotted", [False, True])
+def test_per_block_pipeline_replays_from_a_captured_graph(hf, orc, slotted):
     # per-page histograms -> per-page codebooks -> encode -> decode, captured once
     pages = 24
     n = pages * 16384
@@ -70,7 +71,7 @@ def test_per_block_pipeline_replays_from_a_captured_graph(hf, orc):
     keep = {}
 
     def block():
-        s = system.encode_blocks(t, mode=hf.HF_MODE_HUFFMAN, sync=False)
+        s = system.encode_blocks(t, mode=hf.HF_MODE_HUFFMAN, sync=False, slotted=slotted)
         decoder.decode_blocks(s, out=out, check_stream=False)
         keep["s"] = s
 
@@ -90,7 +91,12 @@ def test_per_block_pipeline_replays_from_a_captured_graph(hf, orc):
         torch.cuda.synchronize()
         ctx.sync()
         assert np.array_equal(out.cpu().numpy(), nxt)
-        payload, off, _, _ = orc.rp_encode_blocks(nxt)
+        if slotted:
+            payload, off, words, _, _ = orc.rp_encode_blocks_slotted(nxt)
+            assert np.array_equal(s.chunk_words[:pages].cpu().numpy().view(np.uint32), words)
+        else:
+            payload, off, _, _ = orc.rp_encode_blocks(nxt)
+        assert np.array_equal(s.chunk_off[: pages + 1].cpu().numpy().view(np.uint32), off)
         total = int(s.chunk_off[pages].item())
         assert total == payload.size
         assert np.array_equal(s.payload[:total].cpu().numpy().view(np.uint32), payload)

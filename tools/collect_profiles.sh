@@ -11,7 +11,7 @@ for k in gauss fp8 uniform geom blocks; do
   cp "$(ls -t $(find gpurun_out/${TAG}_pmc_$k/trace -name '*kernel_stats.csv') | head -n 1)" profiles/${TAG}_pmc_${k}_kernel_stats.csv
 done
 for c in 1 2 3 5 4_shard; do cp gpurun_out/${TAG}_line_config$c.json profiles/${TAG}_bench_line_config$c.json; done
-for f in kprobe kprobe_blocks kprobe_codebook kprobe_fields; do
+for f in kprobe kprobe_blocks kprobe_codebook kprobe_fields kprobe_slotted; do
   grep -v "amdgpu.ids" gpurun_out/${TAG}_$f.txt > profiles/${TAG}_$f.txt
 done
 ls -la profiles/${TAG}_*

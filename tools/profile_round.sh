@@ -22,4 +22,5 @@ timeout -k 10 120 python3 tools/kprobe.py --elems 1073741824 --reps 5 > gpurun_o
 timeout -k 10 120 python3 tools/kprobe_blocks.py --pages 65536 --reps 5 > gpurun_out/${TAG}_kprobe_blocks.txt 2>&1
 timeout -k 10 120 python3 tools/kprobe_codebook.py --blocks 65536 --reps 5 > gpurun_out/${TAG}_kprobe_codebook.txt 2>&1
 timeout -k 10 120 python3 tools/kprobe_fields.py > gpurun_out/${TAG}_kprobe_fields.txt 2>&1
+timeout -k 10 120 python3 tools/kprobe_slotted.py --reps 5 > gpurun_out/${TAG}_kprobe_slotted.txt 2>&1
 echo "profile round $TAG done"
