@@ -604,8 +604,9 @@ hf_k_encode(const void* __restrict__ data, const uint64_t n, const uint32_t nchu
 // Every chunk's place is known before the encoder starts: chunk c owns a slot of
 // HF_SLOT_WORDS(B_c) = ceil(B_c / 32) + 126 words, B_c = sum over the chunk's symbols of their code
 // lengths, which the per-chunk histogram and the chunk's codebook give without reading the data
-// (a lane takes ceil(T / 32) + 1 words for T <= its own bits, and there are 64 lanes: no chunk
-// needs more).  Slot offsets are a prefix sum of the slot sizes.  With the place known, words go
+// (a lane asks for a word only while it holds fewer than 32 bits, so it ends with at most 62
+// unread ones and takes at most floor((T + 62) / 32) words for the T bits of its codes; 64 lanes
+// take at most floor(B_c / 32) + 124: no chunk needs more).  Slot offsets are a prefix sum of the slot sizes.  With the place known, words go
 // straight to global memory as they complete: no staging in LDS, no tile descriptors, no look-back,
 // no scout, and a wavefront needs 1 KiB of LDS for its table instead of 17 KiB -- occupancy is
 // bounded by registers, not LDS, and the per-wavefront latency of the symbol loop is covered by

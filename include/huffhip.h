@@ -287,8 +287,8 @@ int hf_decode_chunks_to(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload
  * d_freq_chunks, the histograms the codebooks were built from, and the codebooks' lengths), which
  * no chunk can outgrow.  d_chunk_off[c] = start of slot c (prefix sum of the slot sizes,
  * nchunks + 1 values, the last one the stream's words), d_chunk_words[c] = words the chunk filled;
- * the rest of a slot is zero.  The stream is 2-4 % larger than the dense one (about 54 words per
- * full chunk) and is written without staging or look-back, at 1.0-1.7x the dense encoder's rate.
+ * the rest of a slot is zero.  The payload is 1.5-3 % larger than the dense one (about 54 words per
+ * full chunk) and is written without staging or look-back, at 1.1-1.45x the dense encoder's rate.
  * It is not a format-v1 payload: hf_container_pack does not take it, and it is decoded by
  * hf_decode_chunks_slotted only.  payload_cap_words >= hf_slotted_bound_words(n) always fits; a
  * smaller buffer that the slots do not fit gives HF_ERR_OVERFLOW and nothing is written.

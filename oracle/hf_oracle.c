@@ -814,6 +814,7 @@ uint64_t orc_rp_slot_blocks(const uint8_t* sym, size_t n, const uint8_t* len,
         for (size_t i = 0; i < m; ++i) bits += len[c * 256 + sym[first + i]];
         const uint64_t slot = ORC_SLOT_WORDS(bits);
         const uint32_t w = chunk_off[c + 1] - chunk_off[c];
+        if (w > slot) return UINT64_MAX;  /* the bound is broken: never seen, never expected */
         slot_off[c] = (uint32_t)at;
         words[c] = w;
         if (slot_payload) {

@@ -171,12 +171,14 @@ uint64_t orc_rp_encode_blocks(const uint8_t* sym, size_t n, uint64_t min_freq_th
 /* Slotted placement of a per-block stream (an alternative to the back-to-back one above, for
  * encoders that want every chunk's place before they start): chunk c gets a slot of
  * ORC_SLOT_WORDS(B_c) = ceil(B_c / 32) + 126 words, B_c = the bits of the chunk's codes
- * (sum over its symbols of len[c][symbol]) -- no chunk needs more: a lane takes
- * ceil(T / 32) + 1 words for T <= its own bits, and there are 64 lanes.  The chunk's words are the
+ * (sum over its symbols of len[c][symbol]) -- no chunk needs more: a lane asks for a word only
+ * while it holds fewer than 32 bits, so it ends with at most 62 unread ones and takes at most
+ * floor((T + 62) / 32) words for the T bits of its codes; 64 lanes: floor(B_c / 32) + 124.  The chunk's words are the
  * same words in the same order; slot_off[c] = sum of the earlier slots, slot_off[nchunks] = their
  * total, words[c] = the words the chunk really has, and the rest of each slot is zero.
  * `payload` / `chunk_off`: the back-to-back stream of orc_rp_encode_blocks.  Returns the total
- * slot words (slot_payload may be NULL to size only). */
+ * slot words (slot_payload may be NULL to size only), UINT64_MAX if a chunk were larger than its
+ * slot. */
 #define ORC_SLOT_WORDS(bits) (((bits) + 31u) / 32u + 126u)
 uint64_t orc_rp_slot_blocks(const uint8_t* sym, size_t n, const uint8_t* len,
                             const uint32_t* payload, const uint32_t* chunk_off,

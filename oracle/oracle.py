@@ -416,6 +416,11 @@ def rp_encode_blocks(sym, thr: int = 0, payload_words: int = 0):
     return payload[:total], off, code[:nch], lens[:nch]
 
 
+def slot_words(bits: int) -> int:
+    """ORC_SLOT_WORDS: words of the slot of a chunk whose codes take `bits` bits."""
+    return (bits + 31) // 32 + 126
+
+
 def rp_encode_blocks_slotted(sym, thr: int = 0):
     """The per-block stream with every chunk in a slot of ceil(bits / 32) + 126 words:
     (payload u32, slot_off u32[nchunks+1], words u32[nchunks], code, len)."""
@@ -429,6 +434,7 @@ def rp_encode_blocks_slotted(sym, thr: int = 0):
     total = int(lib().orc_rp_slot_blocks(_p(sym, _u8p), sym.size, _p(lens_c, _u8p), _p(pay, _u32p),
                                          _p(off, _u32p), None, _p(slot_off, _u32p),
                                          _p(words, _u32p)))
+    assert total != 2**64 - 1, "a chunk outgrew its slot"
     out = np.zeros(max(total, 1), np.uint32)
     lib().orc_rp_slot_blocks(_p(sym, _u8p), sym.size, _p(lens_c, _u8p), _p(pay, _u32p),
                              _p(off, _u32p), _p(out, _u32p), _p(slot_off, _u32p), _p(words, _u32p))

@@ -307,3 +307,37 @@ def test_fp4_pairs_and_bit_planes_round_trip_with_known_answers(orc):
     assert s.tolist() == [0xAA, 0xAA, 0xCC, 0xCC, 0xF0, 0xF0, 0x00, 0xFF] + [0] * 8
     assert orc.container_bytes(1024, orc.LAYOUT_BITPLANE8, 0, 100) == \
         orc.container_bytes(1024, orc.LAYOUT_U8, 0, 100)
+
+
+def test_slotted_placement_keeps_every_chunk_inside_its_slot(orc):
+    # slots are sized from the bits of a chunk's codes alone; the look-ahead words of 64 lanes must
+    # fit the 126 extra words whatever the data
+    rng = np.random.default_rng(77)
+    ch = 16384
+    cases = [rng.integers(0, 256, 3 * ch + 17).astype(np.uint8),
+             np.minimum(rng.geometric(0.5, 4 * ch) - 1, 255).astype(np.uint8),
+             np.full(2 * ch + 1, 9, np.uint8)]
+    # lanes that differ: groups of 8 symbols alternate between a one-bit and a long code
+    lanes = np.where((np.arange(5 * ch) // 8) % 2 == 0, 0, rng.integers(1, 256, 5 * ch)).astype(np.uint8)
+    cases.append(lanes)
+    # one lane (group index = 7 mod 64) all rare symbols, the others one symbol
+    one = np.zeros(3 * ch, np.uint8)
+    g = np.arange(3 * ch) // 8
+    one[g % 64 == 7] = rng.integers(1, 256, int((g % 64 == 7).sum()))
+    cases.append(one)
+    for sym in cases:
+        payload, slot_off, words, code, lens = orc.rp_encode_blocks_slotted(sym)
+        dense, off, code2, lens2 = orc.rp_encode_blocks(sym)
+        nch = orc.num_chunks(sym.size)
+        assert np.array_equal(code, code2) and np.array_equal(lens, lens2)
+        assert np.array_equal(np.diff(off.astype(np.int64)), words.astype(np.int64))
+        for c in range(nch):
+            part = sym[c * ch:(c + 1) * ch]
+            bits = int(lens[c][part].astype(np.int64).sum())
+            slot = int(slot_off[c + 1]) - int(slot_off[c])
+            assert slot == orc.slot_words(bits)
+            assert int(words[c]) <= bits // 32 + 124 <= slot
+            a = int(slot_off[c])
+            assert np.array_equal(payload[a:a + int(words[c])], dense[off[c]:off[c + 1]])
+            assert not payload[a + int(words[c]):a + slot].any()
+        assert payload.size == int(slot_off[nch])
