@@ -311,6 +311,21 @@ def test_seeded_random_pages_against_the_oracle(hf, orc):
             assert (m, ent) == (books[c][2], books[c][3])
             assert np.array_equal(code, books[c][0]) and np.array_equal(lens, books[c][1]), c
         assert torch.equal(hf.ParrallelHuffmanDecoder().decode(s), t)
+        # the same pages in slots sized from each page's counts and code lengths
+        ss = sys_.encode_blocks(t, mode=mode, slotted=True)
+        words = np.diff(off.astype(np.int64))
+        slots = np.array([orc.slot_words(int(books[c][1][sym[c * CH:(c + 1) * CH]].astype(np.int64).sum()))
+                          for c in range(P)], np.int64)
+        starts = np.concatenate([[0], np.cumsum(slots)])
+        assert ss.total_words == int(starts[P])
+        assert np.array_equal(ss.chunk_off[: P + 1].cpu().numpy().view(np.uint32), starts)
+        assert np.array_equal(ss.chunk_words[:P].cpu().numpy().view(np.uint32), words)
+        got = ss.payload[: ss.total_words].cpu().numpy().view(np.uint32)
+        for c in range(P):
+            a = int(starts[c])
+            assert np.array_equal(got[a:a + int(words[c])], payload[off[c]:off[c + 1]]), c
+            assert not got[a + int(words[c]):int(starts[c + 1])].any(), c
+        assert torch.equal(hf.ParrallelHuffmanDecoder().decode(ss), t)
     # HF_MODE_BEST: per page, Huffman only where it pays; the stream still round-trips
     s = sys_.encode_blocks(t, mode=hf.HF_MODE_BEST)
     for c in range(P):
