@@ -104,6 +104,15 @@ trait HuffHip extends Library {
                                layout: Int, dChunkCodebooks: Pointer, dChunkIds: Pointer,
                                dOutSlots: Pointer, nIds: Long, dOut: Pointer, nSlots: Long,
                                check: Int): Int
+  // the same placement with one codebook for the stream: count per chunk, fold, build, encode
+  def hf_symbol_stat_fold_dev(ctx: Pointer, dFreqChunks: Pointer, nChunks: Long, dFreq256: Pointer): Int
+  def hf_encode_slotted(ctx: Pointer, dData: Pointer, n: Long, layout: Int, dCodebook: Pointer,
+                        dFreqChunks: Pointer, dSide: Pointer, dPayload: Pointer,
+                        payloadCapWords: Long, dChunkOff: Pointer, dChunkWords: Pointer,
+                        hTotalWords: LongByReference): Int
+  def hf_decode_slotted(ctx: Pointer, dPayload: Pointer, payloadWords: Long, dChunkOff: Pointer,
+                        dChunkWords: Pointer, dSide: Pointer, n: Long, layout: Int,
+                        dCodebook: Pointer, dOut: Pointer, check: Int): Int
   def hf_chunk_codebook_download(ctx: Pointer, dChunkCodebooks: Pointer, chunk: Long,
                                  hCode: Array[Short], hLen: Array[Byte], mode: IntByReference,
                                  entropy: IntByReference): Int

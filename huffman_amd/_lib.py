@@ -117,6 +117,11 @@ SIGNATURES = {
                                            C.c_uint64, _vp, _vp, _u64p]),
     "hf_decode_chunks_slotted": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp, C.c_uint64, C.c_int,
                                            _vp, _vp, _vp, C.c_uint64, _vp, C.c_uint64, C.c_int]),
+    "hf_symbol_stat_fold_dev": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
+    "hf_encode_slotted": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, _vp, _vp, _vp, _vp, C.c_uint64,
+                                    _vp, _vp, _u64p]),
+    "hf_decode_slotted": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp, C.c_uint64, C.c_int, _vp,
+                                    _vp, C.c_int]),
     "hf_chunk_codebook_download": (C.c_int, [_vp, _vp, C.c_uint64, _u16p, _u8p, _ip, _u32p]),
     "hf_container_plan": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_uint64,
                                     C.POINTER(hf_container_info)]),

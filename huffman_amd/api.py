@@ -567,16 +567,62 @@ class EntropyAwareHuffmanSystem(_Module):
 
     # -- whole path ----------------------------------------------------------------------------
     def encode(self, data_in: torch.Tensor, mode: int = HF_MODE_AUTO,
-               layout: Optional[int] = None, min_freq_threshold: int = 0) -> EncodedStream:
+               layout: Optional[int] = None, min_freq_threshold: int = 0,
+               slotted: bool = False) -> EncodedStream:
+        """``slotted``: one codebook for the stream, every chunk in a slot sized from the chunk's
+        own counts (``hf_encode_slotted``): 1.5-3 % more words, written faster, no container."""
         data_in = data_in.contiguous()
         if layout in FIELD_LAYOUTS:
             sym, side = self.split_fields(data_in, layout)
-            s = self.encode(sym, mode, HF_LAYOUT_U8, min_freq_threshold)
+            s = self.encode(sym, mode, HF_LAYOUT_U8, min_freq_threshold, slotted)
             s.layout, s.side, s.dtype = layout, side, data_in.dtype
             return s
+        if slotted:
+            return self._encode_slotted(data_in, mode, layout, min_freq_threshold)
         freq = self.histogram(data_in, layout)
         cb = self.codebook(freq, mode, min_freq_threshold)
         return self.encode_with(data_in, cb, layout)
+
+    def _encode_slotted(self, data_in, mode, layout, min_freq_threshold) -> EncodedStream:
+        lay = layout_of(data_in) if layout is None else layout
+        n, dev, h = data_in.numel(), data_in.device, self.ctx.handle
+        nch = (n + HF_CHUNK_SYMS - 1) // HF_CHUNK_SYMS
+        with torch.cuda.stream(self.ctx.stream):
+            freq = torch.zeros(256, dtype=torch.int64, device=dev)
+        freq_chunks = torch.empty(max(1, nch) * 256, dtype=torch.int32, device=dev)
+        check(L.lib().hf_symbol_stat_chunks_dev(h, C.c_void_p(_dev_ptr(data_in)), n, lay,
+                                                C.c_void_p(freq_chunks.data_ptr())),
+              "hf_symbol_stat_chunks_dev")
+        check(L.lib().hf_symbol_stat_fold_dev(h, C.c_void_p(freq_chunks.data_ptr()), nch,
+                                              C.c_void_p(freq.data_ptr())),
+              "hf_symbol_stat_fold_dev")
+        cb = self.codebook(freq, mode, min_freq_threshold)
+        chunk_off = torch.empty(((nch + 1 + 3) // 4) * 4, dtype=torch.int32, device=dev)
+        chunk_words = torch.empty(((nch + 3) // 4) * 4 + 4, dtype=torch.int32, device=dev)
+        side = torch.empty(max(16, n), dtype=torch.uint8, device=dev) \
+            if lay == HF_LAYOUT_BF16_EXP else None
+        total = C.c_uint64(0)
+
+        def run(buf):
+            return L.lib().hf_encode_slotted(
+                h, C.c_void_p(_dev_ptr(data_in)), n, lay, C.c_void_p(cb.ptr),
+                C.c_void_p(freq_chunks.data_ptr()), C.c_void_p(_dev_ptr(side)),
+                C.c_void_p(buf.data_ptr()), buf.numel(), C.c_void_p(chunk_off.data_ptr()),
+                C.c_void_p(chunk_words.data_ptr()), C.byref(total))
+        # (a codebook built from the stream's own counts averages <= 8 bits per symbol over the
+        # stream, not over every chunk: size for the average plus slack, then for the worst case)
+        payload = torch.empty(max(16, nch * int(L.HF_SLOT_WORDS(HF_CHUNK_SYMS * 8))),
+                              dtype=torch.int32, device=dev)
+        rc = run(payload)
+        if rc == L.HF_ERR_OVERFLOW:
+            payload = torch.empty(max(16, int(L.lib().hf_slotted_bound_words(n))),
+                                  dtype=torch.int32, device=dev)
+            rc = run(payload)
+        check(rc, "hf_encode_slotted")
+        return EncodedStream(n=n, layout=lay, dtype=data_in.dtype, payload=payload,
+                             chunk_off=chunk_off, side=side, codebook=cb,
+                             total_words=int(total.value), chunk_freq=freq_chunks,
+                             chunk_words=chunk_words)
 
     # -- per-block codebooks (one codebook per 16384-symbol chunk, e.g. a KV-cache page) --------
     def encode_blocks(self, data_in: torch.Tensor, mode: int = HF_MODE_AUTO,
@@ -784,6 +830,13 @@ class ParrallelHuffmanDecoder(_Module):  # spelling as in decoder/top_decoder.sc
             return self._merge_fields(s, sym, out)
         if out is None:
             out = torch.empty(max(s.n, 16), dtype=s.dtype, device=s.payload.device)
+        if s.chunk_words is not None:
+            check(L.lib().hf_decode_slotted(
+                self.ctx.handle, C.c_void_p(s.payload.data_ptr()), s.payload.numel(),
+                C.c_void_p(s.chunk_off.data_ptr()), C.c_void_p(s.chunk_words.data_ptr()),
+                C.c_void_p(_dev_ptr(s.side)), s.n, s.layout, C.c_void_p(s.codebook.ptr),
+                C.c_void_p(_dev_ptr(out)), 1 if check_stream else 0), "hf_decode_slotted")
+            return out[:s.n]
         check(L.lib().hf_decode(self.ctx.handle, C.c_void_p(s.payload.data_ptr()),
                                 s.payload.numel(), C.c_void_p(s.chunk_off.data_ptr()),
                                 C.c_void_p(_dev_ptr(s.side)), s.n, s.layout,

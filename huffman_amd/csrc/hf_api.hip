@@ -744,18 +744,20 @@ uint64_t hf_slotted_bound_words(uint64_t n) {
     return hf_num_chunks(n) * (uint64_t)HF_SLOT_WORDS(HF_CHUNK_SYMS * 16u);
 }
 
-int hf_encode_chunks_slotted(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
-                             const void* d_chunk_codebooks, const uint32_t* d_freq_chunks,
-                             uint8_t* d_side, uint32_t* d_payload, uint64_t payload_cap_words,
-                             uint32_t* d_chunk_off, uint32_t* d_chunk_words,
-                             uint64_t* h_total_words) {
+// d_codebook: per_chunk ? hf_chunk_cb records : one hf_cb_dev (both begin with their code table)
+static int encode_slotted_common(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
+                                 const void* d_codebook, bool per_chunk,
+                                 const uint32_t* d_freq_chunks, uint8_t* d_side,
+                                 uint32_t* d_payload, uint64_t payload_cap_words,
+                                 uint32_t* d_chunk_off, uint32_t* d_chunk_words,
+                                 uint64_t* h_total_words) {
     if (!ctx || !d_chunk_off || !layout_ok(layout)) return HF_ERR_ARG;
-    if (n && (!d_data || !d_payload || !d_chunk_codebooks || !d_freq_chunks || !d_chunk_words))
+    if (n && (!d_data || !d_payload || !d_codebook || !d_freq_chunks || !d_chunk_words))
         return HF_ERR_ARG;
     const int lay = norm_layout(layout);
     if (lay == HF_LAYOUT_BF16_EXP && n && !d_side) return HF_ERR_ARG;
     if (!aligned16(d_data) || !aligned16(d_side) || !aligned16(d_payload) ||
-        !aligned16(d_chunk_off) || !aligned16(d_chunk_words) || !aligned16(d_chunk_codebooks) ||
+        !aligned16(d_chunk_off) || !aligned16(d_chunk_words) || !aligned16(d_codebook) ||
         !aligned16(d_freq_chunks))
         return HF_ERR_ALIGN;
     if (n > (1ull << 40)) return HF_ERR_RANGE;
@@ -780,8 +782,12 @@ int hf_encode_chunks_slotted(hf_ctx* ctx, const void* d_data, uint64_t n, int la
         zero_words(d_chunk_off, 1, ctx->stream);
     } else {
         tic(ctx);
+        static_assert(offsetof(hf_chunk_cb, enc) == 0 && offsetof(hf_cb_dev, enc) == 0 &&
+                          sizeof(hf_chunk_cb) % 4 == 0,
+                      "a record's code table is its first kilobyte");
         hf_launch_encode_chunks_slotted(d_data, n, lay,
-                                        reinterpret_cast<const hf_chunk_cb*>(d_chunk_codebooks),
+                                        reinterpret_cast<const uint32_t*>(d_codebook),
+                                        per_chunk ? (uint32_t)(sizeof(hf_chunk_cb) / 4) : 0u,
                                         d_freq_chunks, d_side, d_payload, payload_cap_words,
                                         d_chunk_off, d_chunk_words, ctx->d_scan_aux, ctx->d_spill,
                                         ctx->d_ctl + 1, ctx->num_cu, ctx->stream);
@@ -795,6 +801,42 @@ int hf_encode_chunks_slotted(hf_ctx* ctx, const void* d_data, uint64_t n, int la
         HF_HIP(hipStreamSynchronize(ctx->stream));
         *h_total_words = nchunks ? ctx->h_ctl[2] : 0;
         return report_kernel_errors(ctx);
+    }
+    return HF_OK;
+}
+
+int hf_encode_chunks_slotted(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
+                             const void* d_chunk_codebooks, const uint32_t* d_freq_chunks,
+                             uint8_t* d_side, uint32_t* d_payload, uint64_t payload_cap_words,
+                             uint32_t* d_chunk_off, uint32_t* d_chunk_words,
+                             uint64_t* h_total_words) {
+    return encode_slotted_common(ctx, d_data, n, layout, d_chunk_codebooks, true, d_freq_chunks,
+                                 d_side, d_payload, payload_cap_words, d_chunk_off, d_chunk_words,
+                                 h_total_words);
+}
+
+int hf_encode_slotted(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
+                      const void* d_codebook, const uint32_t* d_freq_chunks, uint8_t* d_side,
+                      uint32_t* d_payload, uint64_t payload_cap_words, uint32_t* d_chunk_off,
+                      uint32_t* d_chunk_words, uint64_t* h_total_words) {
+    return encode_slotted_common(ctx, d_data, n, layout, d_codebook, false, d_freq_chunks, d_side,
+                                 d_payload, payload_cap_words, d_chunk_off, d_chunk_words,
+                                 h_total_words);
+}
+
+int hf_symbol_stat_fold_dev(hf_ctx* ctx, const uint32_t* d_freq_chunks, uint64_t nchunks,
+                            uint64_t* d_freq256) {
+    if (!ctx || (nchunks && (!d_freq_chunks || !d_freq256))) return HF_ERR_ARG;
+    if (!aligned16(d_freq_chunks) || !aligned16(d_freq256)) return HF_ERR_ALIGN;
+    if (nchunks > (1ull << 26)) return HF_ERR_RANGE;
+    HF_USE_DEVICE(ctx);
+    if (nchunks) {
+        tic(ctx);
+        hf_launch_fold_chunks(d_freq_chunks, nchunks,
+                              reinterpret_cast<unsigned long long*>(d_freq256), ctx->stream);
+        const hipError_t launch_err = hipGetLastError();
+        toc(ctx);
+        HF_HIP(launch_err);
     }
     return HF_OK;
 }
@@ -830,22 +872,23 @@ int hf_chunk_codebook_download(hf_ctx* ctx, const void* d_chunk_codebooks, uint6
 }
 
 /* ---- decoder ------------------------------------------------------------------------------------- */
-int hf_decode(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
-              const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n, int layout,
-              const void* d_codebook, void* d_out, int check) {
+static int decode_common(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
+                         const uint32_t* d_chunk_off, const uint32_t* d_chunk_words,
+                         const uint8_t* d_side, uint64_t n, int layout, const void* d_codebook,
+                         void* d_out, int check) {
     if (!ctx || !d_codebook || !layout_ok(layout)) return HF_ERR_ARG;
     if (n && (!d_payload || !d_chunk_off || !d_out)) return HF_ERR_ARG;
     if (n && payload_words < 4) return HF_ERR_ARG;  // the kernel reads the buffer 16 bytes at a time
     const int lay = norm_layout(layout);
     if (lay == HF_LAYOUT_BF16_EXP && n && !d_side) return HF_ERR_ARG;
     if (!aligned16(d_payload) || !aligned16(d_side) || !aligned16(d_out) ||
-        !aligned16(d_chunk_off) || !aligned16(d_codebook))
+        !aligned16(d_chunk_off) || !aligned16(d_codebook) || !aligned16(d_chunk_words))
         return HF_ERR_ALIGN;
     if (n > (1ull << 40)) return HF_ERR_RANGE;
     HF_USE_DEVICE(ctx);
     if (n) {
         tic(ctx);
-        hf_launch_decode(d_payload, payload_words, d_chunk_off, d_side, n, lay,
+        hf_launch_decode(d_payload, payload_words, d_chunk_off, d_chunk_words, d_side, n, lay,
                          reinterpret_cast<const hf_cb_dev*>(d_codebook), d_out, ctx->d_ctl + 1,
                          ctx->num_cu, ctx->stream);
         const hipError_t launch_err = hipGetLastError();  // before the event record can mask it
@@ -858,6 +901,22 @@ int hf_decode(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
         return report_kernel_errors(ctx);
     }
     return HF_OK;
+}
+
+int hf_decode(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
+              const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n, int layout,
+              const void* d_codebook, void* d_out, int check) {
+    return decode_common(ctx, d_payload, payload_words, d_chunk_off, nullptr, d_side, n, layout,
+                         d_codebook, d_out, check);
+}
+
+int hf_decode_slotted(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
+                      const uint32_t* d_chunk_off, const uint32_t* d_chunk_words,
+                      const uint8_t* d_side, uint64_t n, int layout, const void* d_codebook,
+                      void* d_out, int check) {
+    if (n && !d_chunk_words) return HF_ERR_ARG;
+    return decode_common(ctx, d_payload, payload_words, d_chunk_off, d_chunk_words, d_side, n,
+                         layout, d_codebook, d_out, check);
 }
 
 /* ---- container ---------------------------------------------------------------------------------- */

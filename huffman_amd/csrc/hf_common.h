@@ -117,11 +117,14 @@ void hf_launch_encode(const void* d_data, uint64_t n, int layout, const hf_cb_de
 size_t hf_encode_spill_bytes(int num_cu);
 size_t hf_scan_aux_bytes(uint64_t m);
 void hf_launch_encode_chunks_slotted(const void* d_data, uint64_t n, int layout,
-                                     const hf_chunk_cb* cbs, const uint32_t* d_freq_chunks,
+                                     const uint32_t* d_enc, uint32_t enc_stride,
+                                     const uint32_t* d_freq_chunks,
                                      uint8_t* d_side, uint32_t* d_payload, uint64_t cap_words,
                                      uint32_t* d_slot_off, uint32_t* d_chunk_words,
                                      unsigned long long* d_scan_aux, uint32_t* d_dump,
                                      uint32_t* d_err, int num_cu, hipStream_t s);
+void hf_launch_fold_chunks(const uint32_t* d_freq_chunks, uint64_t nchunks,
+                           unsigned long long* d_freq256, hipStream_t s);
 void hf_launch_hist_chunks(const void* d_data, uint64_t n, int layout, uint32_t* d_freq_chunks,
                            hipStream_t s);
 #define HF_CB_BATCH 65536u  // per-block codebooks built per pass through the scratch block
@@ -152,7 +155,8 @@ void hf_launch_fields_split(const void* d_data, uint64_t n, int layout, uint8_t*
 void hf_launch_fields_merge(const uint8_t* d_sym, const uint8_t* d_side, uint64_t n, int layout,
                             void* d_out, hipStream_t s);
 void hf_launch_decode(const uint32_t* d_payload, uint64_t payload_words,
-                      const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n, int layout,
+                      const uint32_t* d_chunk_off, const uint32_t* d_chunk_words,
+                      const uint8_t* d_side, uint64_t n, int layout,
                       const hf_cb_dev* cb, void* d_out, uint32_t* d_err, int num_cu,
                       hipStream_t s);
 

@@ -510,15 +510,22 @@ struct DecLds {
 template <int LAYOUT, class TAB>
 __device__ __forceinline__ void decode_chunks_of_wave(
     const uint32_t* __restrict__ payload, const uint64_t payload_words,
-    const uint32_t* __restrict__ chunk_off, const uint8_t* __restrict__ side, const uint64_t n,
+    const uint32_t* __restrict__ chunk_off, const uint32_t* __restrict__ chunk_words,
+    const uint8_t* __restrict__ side, const uint64_t n,
     const uint32_t nchunks, void* __restrict__ out, const TAB& T, uint32_t* __restrict__ stg,
     uint32_t* err, const uint32_t wave, const uint32_t nwaves, bool staged, const int lane) {
     const size_t elem_bytes = LAYOUT == HF_LAYOUT_BF16_EXP ? 2 : 1;
     for (uint32_t c = wave; c < nchunks; c += nwaves) {
         const uint32_t off0 = __builtin_amdgcn_readfirstlane(chunk_off[c]);
-        const uint32_t off1 = __builtin_amdgcn_readfirstlane(chunk_off[c + 1]);
+        uint32_t off1 = __builtin_amdgcn_readfirstlane(chunk_off[c + 1]);
         // offsets that run backwards or past the payload buffer are never followed
-        const bool sane = off1 >= off0 && (uint64_t)off1 <= payload_words;
+        bool sane = off1 >= off0 && (uint64_t)off1 <= payload_words;
+        if (chunk_words) {
+            // a slotted stream: the chunk's words are the first chunk_words[c] of its slot
+            const uint32_t w = __builtin_amdgcn_readfirstlane(chunk_words[c]);
+            sane = sane && w <= off1 - off0;
+            off1 = off0 + w;
+        }
         if (!sane) {
             if (lane == 0) atomicOr(err, HF_KERR_CORRUPT);
             staged = false;
@@ -545,7 +552,8 @@ __device__ __forceinline__ void decode_chunks_of_wave(
 template <int LAYOUT>
 __global__ __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 6))) void
 hf_k_decode(const uint32_t* __restrict__ payload, const uint64_t payload_words,
-            const uint32_t* __restrict__ chunk_off, const uint8_t* __restrict__ side,
+            const uint32_t* __restrict__ chunk_off, const uint32_t* __restrict__ chunk_words,
+            const uint8_t* __restrict__ side,
             const uint64_t n, const uint32_t nchunks, const hf_cb_dev* __restrict__ cb,
             void* __restrict__ out, uint32_t* err) {
     extern __shared__ __attribute__((aligned(16))) unsigned char hf_dec_smem[];
@@ -580,7 +588,13 @@ hf_k_decode(const uint32_t* __restrict__ payload, const uint64_t payload_words,
                                    "one of the second level per thread");
     const uint32_t cw = wave < nchunks ? wave : nchunks - 1u;  // (nchunks >= 1)
     const uint32_t o0 = __builtin_amdgcn_readfirstlane(chunk_off[cw]);
-    const uint32_t o1 = __builtin_amdgcn_readfirstlane(chunk_off[cw + 1]);
+    uint32_t o1 = __builtin_amdgcn_readfirstlane(chunk_off[cw + 1]);
+    bool slot_ok = true;
+    if (chunk_words) {  // a slotted stream (see decode_chunks_of_wave)
+        const uint32_t w = __builtin_amdgcn_readfirstlane(chunk_words[cw]);
+        slot_ok = o1 >= o0 && w <= o1 - o0;
+        o1 = o0 + w;
+    }
     const uint32_t n_sub = (uint32_t)__builtin_amdgcn_readfirstlane((int)cb->n_sub);
     const bool pairs = kPairsPossible && n_sub <= kSubPair &&
                        (uint32_t)__builtin_amdgcn_readfirstlane((int)cb->pair_hits) >= HF_PAIR_HITS_MIN;
@@ -592,7 +606,7 @@ hf_k_decode(const uint32_t* __restrict__ payload, const uint64_t payload_words,
     const uint4 t_a = t_src[has_a ? threadIdx.x : 0];
     const uint4 t_b = t_src[has_b ? threadIdx.x + kThreads : 0];
     const uint32_t nsub = n_sub < kSubAll ? n_sub : kSubAll;
-    bool staged = wave < nchunks && o1 >= o0 && (uint64_t)o1 <= payload_words;
+    bool staged = wave < nchunks && slot_ok && o1 >= o0 && (uint64_t)o1 <= payload_words;
     uint4 w[kStageWords / 256];
     stage_window_load<kStageWords>(payload, payload_words, staged ? o1 : 0u,
                                    staged ? (u64)o0 & ~3ull : 0ull, lane, w);
@@ -607,12 +621,12 @@ hf_k_decode(const uint32_t* __restrict__ payload, const uint64_t payload_words,
     __syncthreads();
     if (kPairsPossible && pairs) {
         PairTables T;
-        decode_chunks_of_wave<LAYOUT>(payload, payload_words, chunk_off, side, n, nchunks, out, T,
-                                      stg, err, wave, nwaves, staged, lane);
+        decode_chunks_of_wave<LAYOUT>(payload, payload_words, chunk_off, chunk_words, side, n,
+                                      nchunks, out, T, stg, err, wave, nwaves, staged, lane);
     } else {
         DecTables<kSubAddr> T;
-        decode_chunks_of_wave<LAYOUT>(payload, payload_words, chunk_off, side, n, nchunks, out, T,
-                                      stg, err, wave, nwaves, staged, lane);
+        decode_chunks_of_wave<LAYOUT>(payload, payload_words, chunk_off, chunk_words, side, n,
+                                      nchunks, out, T, stg, err, wave, nwaves, staged, lane);
     }
 }
 
@@ -862,7 +876,8 @@ void hf_launch_decode_chunks(const uint32_t* d_payload, uint64_t payload_words,
 }
 
 void hf_launch_decode(const uint32_t* d_payload, uint64_t payload_words,
-                      const uint32_t* d_chunk_off, const uint8_t* d_side, uint64_t n, int layout,
+                      const uint32_t* d_chunk_off, const uint32_t* d_chunk_words,
+                      const uint8_t* d_side, uint64_t n, int layout,
                       const hf_cb_dev* cb, void* d_out, uint32_t* d_err, int num_cu,
                       hipStream_t s) {
     const uint64_t nchunks = (n + HF_CHUNK_SYMS - 1) / HF_CHUNK_SYMS;
@@ -878,9 +893,9 @@ void hf_launch_decode(const uint32_t* d_payload, uint64_t payload_words,
     if (layout == HF_LAYOUT_BF16_EXP)
         hipLaunchKernelGGL(hf_k_decode<HF_LAYOUT_BF16_EXP>, dim3((unsigned)grid),
                            dim3(kWaves * 64), lds, s, d_payload, payload_words, d_chunk_off,
-                           d_side, n, (uint32_t)nchunks, cb, d_out, d_err);
+                           d_chunk_words, d_side, n, (uint32_t)nchunks, cb, d_out, d_err);
     else
         hipLaunchKernelGGL(hf_k_decode<HF_LAYOUT_U8>, dim3((unsigned)grid), dim3(kWaves * 64), lds,
-                           s, d_payload, payload_words, d_chunk_off, (const uint8_t*)nullptr, n,
-                           (uint32_t)nchunks, cb, d_out, d_err);
+                           s, d_payload, payload_words, d_chunk_off, d_chunk_words,
+                           (const uint8_t*)nullptr, n, (uint32_t)nchunks, cb, d_out, d_err);
 }

@@ -612,9 +612,12 @@ hf_k_encode(const void* __restrict__ data, const uint64_t n, const uint32_t nchu
 // bounded by registers, not LDS, and the per-wavefront latency of the symbol loop is covered by
 // the other wavefronts.  What a slot has left over is zeroed.
 
-// slot size of every chunk into slot[c]; slot[nchunks] = 0 (the scan turns it into the total)
+// slot size of every chunk into slot[c]; slot[nchunks] = 0 (the scan turns it into the total).
+// enc: the code table (code | len << 16 by symbol) of chunk 0; chunk c's lies enc_stride words
+// further per chunk (0: one table for the whole stream).
 __global__ __launch_bounds__(256) void hf_k_slot_sizes(const uint32_t* __restrict__ freq_chunks,
-                                                       const hf_chunk_cb* __restrict__ cbs,
+                                                       const uint32_t* __restrict__ enc,
+                                                       const uint32_t enc_stride,
                                                        const uint32_t nchunks,
                                                        uint32_t* __restrict__ slot) {
     const int lane = hf_lane();
@@ -625,7 +628,7 @@ __global__ __launch_bounds__(256) void hf_k_slot_sizes(const uint32_t* __restric
         return;
     }
     const uint4 f = reinterpret_cast<const uint4*>(freq_chunks + (size_t)c * 256)[lane];
-    const uint4 e = reinterpret_cast<const uint4*>(cbs[c].enc)[lane];
+    const uint4 e = reinterpret_cast<const uint4*>(enc + (size_t)c * enc_stride)[lane];
     uint32_t bits = f.x * (e.x >> 16) + f.y * (e.y >> 16) + f.z * (e.z >> 16) + f.w * (e.w >> 16);
     bits = hf_wave_sum_u32(bits);  // <= 16384 * 16
     if (lane == 0) slot[c] = HF_SLOT_WORDS(bits);
@@ -711,7 +714,7 @@ __global__ __launch_bounds__(256) void hf_k_scan_add(uint32_t* __restrict__ a, c
 template <int LAYOUT>
 __global__ __launch_bounds__(256) void hf_k_encode_slotted(
     const void* __restrict__ data, const uint64_t n, const uint32_t nchunks,
-    const hf_chunk_cb* __restrict__ cbs, uint8_t* __restrict__ side,
+    const uint32_t* __restrict__ enc_src, const uint32_t enc_stride, uint8_t* __restrict__ side,
     uint32_t* __restrict__ payload, const uint32_t* __restrict__ slot_off,
     uint32_t* __restrict__ chunk_words, uint32_t* __restrict__ dump,
     const u64* __restrict__ total_words, const u64 limit, uint32_t* err) {
@@ -725,6 +728,7 @@ __global__ __launch_bounds__(256) void hf_k_encode_slotted(
     const uint32_t enc_tab = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(enc));
     const size_t elem_bytes = LAYOUT == HF_LAYOUT_BF16_EXP ? 2 : 1;
     const uint32_t nwaves = gridDim.x * 4u;
+    bool have_table = false;
     for (uint32_t c = blockIdx.x * 4u + (uint32_t)wave; c < nchunks; c += nwaves) {
         const uint64_t first = (uint64_t)c * HF_CHUNK_SYMS;
         const uint64_t left = n - first;
@@ -733,12 +737,15 @@ __global__ __launch_bounds__(256) void hf_k_encode_slotted(
         uint8_t* side_chunk = side ? side + first : nullptr;
         const uint32_t off0 = __builtin_amdgcn_readfirstlane(slot_off[c]);
         const uint32_t slot = __builtin_amdgcn_readfirstlane(slot_off[c + 1]) - off0;
-        const hf_chunk_cb* ccb = cbs + c;
+        if (enc_stride != 0 || !have_table) {  // (a stream-wide table is fetched once)
+            const uint32_t* src = enc_src + (size_t)c * enc_stride;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) enc[lane + 64 * k] = ccb->enc[lane + 64 * k];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int k = 0; k < 4; ++k) enc[lane + 64 * k] = src[lane + 64 * k];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            have_table = true;
+        }
         // The slot plays the staging area's part: words below its size land in it.  A word beyond
         // it -- the counts were not this chunk's -- goes to a dump area of one chunk's maximum
         // size that all wavefronts share (what it holds is never read), so nothing is written
@@ -761,7 +768,7 @@ __global__ __launch_bounds__(256) void hf_k_encode_slotted(
         }
         if (lane == 0) chunk_words[c] = total;
         for (uint32_t k = total + (uint32_t)lane; k < slot; k += 64u) dst[k] = 0u;
-        // the table is rewritten for the next chunk: all lookups of this one are done
+        // a per-chunk table is rewritten for the next chunk: all lookups of this one are done
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -774,9 +781,11 @@ size_t hf_scan_aux_bytes(uint64_t m) {
     return (size_t)((m + kScanPerGroup - 1) / kScanPerGroup + 1) * sizeof(u64);
 }
 
-// slot sizes -> slot offsets (in d_slot_off, nchunks + 1 values) -> chunks encoded in their slots
+// slot sizes -> slot offsets (in d_slot_off, nchunks + 1 values) -> chunks encoded in their slots.
+// d_enc / enc_stride: see hf_k_slot_sizes.
 void hf_launch_encode_chunks_slotted(const void* d_data, uint64_t n, int layout,
-                                     const hf_chunk_cb* cbs, const uint32_t* d_freq_chunks,
+                                     const uint32_t* d_enc, uint32_t enc_stride,
+                                     const uint32_t* d_freq_chunks,
                                      uint8_t* d_side, uint32_t* d_payload, uint64_t cap_words,
                                      uint32_t* d_slot_off, uint32_t* d_chunk_words,
                                      unsigned long long* d_scan_aux, uint32_t* d_dump,
@@ -787,7 +796,7 @@ void hf_launch_encode_chunks_slotted(const void* d_data, uint64_t n, int layout,
     const uint64_t m = nchunks + 1;
     const unsigned ngroups = (unsigned)((m + kScanPerGroup - 1) / kScanPerGroup);
     hipLaunchKernelGGL(hf_k_slot_sizes, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, s, d_freq_chunks,
-                       cbs, (uint32_t)nchunks, d_slot_off);
+                       d_enc, enc_stride, (uint32_t)nchunks, d_slot_off);
     hipLaunchKernelGGL(hf_k_scan_local, dim3(ngroups), dim3(256), 0, s, d_slot_off, m, d_scan_aux);
     hipLaunchKernelGGL(hf_k_scan_groups, dim3(1), dim3(256), 0, s, d_scan_aux, ngroups);
     const u64 limit = cap_words < 0xFFFFFFFFull ? cap_words : 0xFFFFFFFFull;
@@ -801,11 +810,11 @@ void hf_launch_encode_chunks_slotted(const void* d_data, uint64_t n, int layout,
     if (grid > cap) grid = cap;
     if (layout == HF_LAYOUT_BF16_EXP)
         hipLaunchKernelGGL(hf_k_encode_slotted<HF_LAYOUT_BF16_EXP>, dim3((unsigned)grid), dim3(256),
-                           0, s, d_data, n, (uint32_t)nchunks, cbs, d_side, d_payload, d_slot_off,
+                           0, s, d_data, n, (uint32_t)nchunks, d_enc, enc_stride, d_side, d_payload, d_slot_off,
                            d_chunk_words, d_dump, d_total, limit, d_err);
     else
         hipLaunchKernelGGL(hf_k_encode_slotted<HF_LAYOUT_U8>, dim3((unsigned)grid), dim3(256), 0, s,
-                           d_data, n, (uint32_t)nchunks, cbs, (uint8_t*)nullptr, d_payload,
+                           d_data, n, (uint32_t)nchunks, d_enc, enc_stride, (uint8_t*)nullptr, d_payload,
                            d_slot_off, d_chunk_words, d_dump, d_total, limit, d_err);
 }
 

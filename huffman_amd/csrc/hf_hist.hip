@@ -183,6 +183,51 @@ __global__ __launch_bounds__(kChunkWaves * 64) void hf_k_hist_chunks(
 
 }  // namespace
 
+// Per-chunk counts folded into a stream's: a workgroup per run of chunks, each of its four
+// wavefronts takes every fourth row (256 counts, 16 bytes per lane), the four partial sums meet in
+// LDS, and thread t adds bin t with one 64-bit atomic.
+namespace {
+constexpr uint32_t kFoldChunks = 64;
+__global__ __launch_bounds__(256) void hf_k_fold_chunks(const uint32_t* __restrict__ freq_chunks,
+                                                        const uint64_t nchunks,
+                                                        unsigned long long* __restrict__ freq256) {
+    __shared__ unsigned long long part[4][256];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint64_t c0 = (uint64_t)blockIdx.x * kFoldChunks;
+    const uint64_t c1 = c0 + kFoldChunks < nchunks ? c0 + kFoldChunks : nchunks;
+    unsigned long long acc[4] = {0, 0, 0, 0};
+    uint64_t c = c0 + wv;
+    for (; c + 12 < c1; c += 16) {  // four rows in flight per wavefront
+        uint4 r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            r[k] = reinterpret_cast<const uint4*>(freq_chunks + (c + 4 * k) * 256)[lane];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            acc[0] += r[k].x, acc[1] += r[k].y, acc[2] += r[k].z, acc[3] += r[k].w;
+        }
+    }
+    for (; c < c1; c += 4) {
+        const uint4 r = reinterpret_cast<const uint4*>(freq_chunks + c * 256)[lane];
+        acc[0] += r.x, acc[1] += r.y, acc[2] += r.z, acc[3] += r.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) part[wv][lane * 4 + k] = acc[k];
+    __syncthreads();
+    const unsigned long long sum = part[0][threadIdx.x] + part[1][threadIdx.x] +
+                                   part[2][threadIdx.x] + part[3][threadIdx.x];
+    if (sum) atomicAdd(&freq256[threadIdx.x], sum);
+}
+}  // namespace
+
+void hf_launch_fold_chunks(const uint32_t* d_freq_chunks, uint64_t nchunks,
+                           unsigned long long* d_freq256, hipStream_t s) {
+    if (nchunks == 0) return;
+    const unsigned grid = (unsigned)((nchunks + kFoldChunks - 1) / kFoldChunks);
+    hipLaunchKernelGGL(hf_k_fold_chunks, dim3(grid), dim3(256), 0, s, d_freq_chunks, nchunks,
+                       d_freq256);
+}
+
 void hf_launch_hist_chunks(const void* d_data, uint64_t n, int layout, uint32_t* d_freq_chunks,
                            hipStream_t s) {
     const uint64_t nchunks = (n + HF_CHUNK_SYMS - 1) / HF_CHUNK_SYMS;

@@ -302,6 +302,22 @@ int hf_encode_chunks_slotted(hf_ctx* ctx, const void* d_data, uint64_t n, int la
                              uint8_t* d_side, uint32_t* d_payload, uint64_t payload_cap_words,
                              uint32_t* d_chunk_off, uint32_t* d_chunk_words,
                              uint64_t* h_total_words);
+/* The same placement for a stream with ONE codebook (hf_system_codebook_dev): the slot sizes
+ * still come from per-chunk histograms, so the caller counts per chunk
+ * (hf_symbol_stat_chunks_dev) and folds those counts into the stream's 256 (hf_symbol_stat_fold_dev
+ * adds them into d_freq256, as hf_symbol_stat_dev adds a tensor's) instead of counting the stream
+ * in one piece.  The chunk words are those hf_encode writes; decoded by hf_decode_slotted only.
+ * No counterpart in the reference, as above. */
+int hf_symbol_stat_fold_dev(hf_ctx* ctx, const uint32_t* d_freq_chunks, uint64_t nchunks,
+                            uint64_t* d_freq256);
+int hf_encode_slotted(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
+                      const void* d_codebook, const uint32_t* d_freq_chunks, uint8_t* d_side,
+                      uint32_t* d_payload, uint64_t payload_cap_words, uint32_t* d_chunk_off,
+                      uint32_t* d_chunk_words, uint64_t* h_total_words);
+int hf_decode_slotted(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
+                      const uint32_t* d_chunk_off, const uint32_t* d_chunk_words,
+                      const uint8_t* d_side, uint64_t n, int layout, const void* d_codebook,
+                      void* d_out, int check);
 /* decodes a slotted stream: all chunks (d_chunk_ids NULL), listed chunks to consecutive pages
  * (d_out_slots NULL), or listed chunks to named pages -- as hf_decode_chunks / hf_decode_chunks_to */
 int hf_decode_chunks_slotted(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,

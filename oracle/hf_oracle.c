@@ -802,7 +802,7 @@ uint64_t orc_rp_encode_blocks(const uint8_t* sym, size_t n, uint64_t min_freq_th
     return pos;
 }
 
-uint64_t orc_rp_slot_blocks(const uint8_t* sym, size_t n, const uint8_t* len,
+uint64_t orc_rp_slot_blocks(const uint8_t* sym, size_t n, const uint8_t* len, size_t len_stride,
                             const uint32_t* payload, const uint32_t* chunk_off,
                             uint32_t* slot_payload, uint32_t* slot_off, uint32_t* words) {
     const size_t nchunks = (n + ORC_CHUNK_SYMS - 1) / ORC_CHUNK_SYMS;
@@ -811,7 +811,7 @@ uint64_t orc_rp_slot_blocks(const uint8_t* sym, size_t n, const uint8_t* len,
         const size_t first = c * ORC_CHUNK_SYMS;
         const size_t m = n - first < ORC_CHUNK_SYMS ? n - first : ORC_CHUNK_SYMS;
         uint64_t bits = 0;
-        for (size_t i = 0; i < m; ++i) bits += len[c * 256 + sym[first + i]];
+        for (size_t i = 0; i < m; ++i) bits += len[c * len_stride + sym[first + i]];
         const uint64_t slot = ORC_SLOT_WORDS(bits);
         const uint32_t w = chunk_off[c + 1] - chunk_off[c];
         if (w > slot) return UINT64_MAX;  /* the bound is broken: never seen, never expected */

@@ -176,11 +176,13 @@ uint64_t orc_rp_encode_blocks(const uint8_t* sym, size_t n, uint64_t min_freq_th
  * floor((T + 62) / 32) words for the T bits of its codes; 64 lanes: floor(B_c / 32) + 124.  The chunk's words are the
  * same words in the same order; slot_off[c] = sum of the earlier slots, slot_off[nchunks] = their
  * total, words[c] = the words the chunk really has, and the rest of each slot is zero.
+ * len_stride: 256 for per-block codebooks (len = nchunks x 256), 0 for one codebook (len = 256
+ * entries; the back-to-back stream is then orc_rp_encode's).
  * `payload` / `chunk_off`: the back-to-back stream of orc_rp_encode_blocks.  Returns the total
  * slot words (slot_payload may be NULL to size only), UINT64_MAX if a chunk were larger than its
  * slot. */
 #define ORC_SLOT_WORDS(bits) (((bits) + 31u) / 32u + 126u)
-uint64_t orc_rp_slot_blocks(const uint8_t* sym, size_t n, const uint8_t* len,
+uint64_t orc_rp_slot_blocks(const uint8_t* sym, size_t n, const uint8_t* len, size_t len_stride,
                             const uint32_t* payload, const uint32_t* chunk_off,
                             uint32_t* slot_payload, uint32_t* slot_off, uint32_t* words);
 int orc_rp_decode_blocks(const uint32_t* payload, const uint32_t* chunk_off, size_t n,

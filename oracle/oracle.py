@@ -98,6 +98,9 @@ def _declare(l: C.CDLL) -> None:
     l.orc_rp_decode.restype = C.c_int
     l.orc_rp_encode_blocks.argtypes = [_u8p, C.c_size_t, C.c_uint64, _u16p, _u8p, _u32p, _u32p]
     l.orc_rp_encode_blocks.restype = C.c_uint64
+    l.orc_rp_slot_blocks.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, _u32p, _u32p, _u32p, _u32p,
+                                     _u32p]
+    l.orc_rp_slot_blocks.restype = C.c_uint64
     l.orc_rp_decode_blocks.argtypes = [_u32p, _u32p, C.c_size_t, _u16p, _u8p, _u8p]
     l.orc_rp_decode_blocks.restype = C.c_int
     l.orc_num_chunks.argtypes = [C.c_size_t]
@@ -427,18 +430,33 @@ def rp_encode_blocks_slotted(sym, thr: int = 0):
     sym = _arr(sym, np.uint8)
     payload, off, code, lens = rp_encode_blocks(sym, thr)
     nch = num_chunks(sym.size)
-    slot_off = np.zeros(nch + 1, np.uint32)
-    words = np.zeros(max(nch, 1), np.uint32)
     lens_c = _arr(lens if nch else np.zeros((1, 256), np.uint8), np.uint8)
     pay = payload if payload.size else np.zeros(1, np.uint32)
-    total = int(lib().orc_rp_slot_blocks(_p(sym, _u8p), sym.size, _p(lens_c, _u8p), _p(pay, _u32p),
-                                         _p(off, _u32p), None, _p(slot_off, _u32p),
-                                         _p(words, _u32p)))
+    out, slot_off, words = _slot(sym, lens_c, 256, pay, off)
+    return out, slot_off, words[:nch], code, lens
+
+
+def _slot(sym, lens, stride, pay, off):
+    nch = num_chunks(sym.size)
+    slot_off = np.zeros(nch + 1, np.uint32)
+    words = np.zeros(max(nch, 1), np.uint32)
+    args = (_p(sym, _u8p), sym.size, _p(lens, _u8p), stride, _p(pay, _u32p), _p(off, _u32p))
+    total = int(lib().orc_rp_slot_blocks(*args, None, _p(slot_off, _u32p), _p(words, _u32p)))
     assert total != 2**64 - 1, "a chunk outgrew its slot"
     out = np.zeros(max(total, 1), np.uint32)
-    lib().orc_rp_slot_blocks(_p(sym, _u8p), sym.size, _p(lens_c, _u8p), _p(pay, _u32p),
-                             _p(off, _u32p), _p(out, _u32p), _p(slot_off, _u32p), _p(words, _u32p))
-    return out[:total], slot_off, words[:nch], code, lens
+    lib().orc_rp_slot_blocks(*args, _p(out, _u32p), _p(slot_off, _u32p), _p(words, _u32p))
+    return out[:total], slot_off, words
+
+
+def rp_encode_slotted(sym, code, lens):
+    """The stream of rp_encode (one codebook) with every chunk in its slot:
+    (payload u32, slot_off u32[nchunks+1], words u32[nchunks])."""
+    sym = _arr(sym, np.uint8)
+    lens = _arr(lens, np.uint8)
+    payload, off = rp_encode(sym, code, lens)
+    pay = payload if payload.size else np.zeros(1, np.uint32)
+    out, slot_off, words = _slot(sym, lens, 0, pay, off)
+    return out, slot_off, words[:num_chunks(sym.size)]
 
 
 def rp_decode_blocks(payload, chunk_off, n: int, code, lens) -> np.ndarray:

@@ -1,4 +1,5 @@
-"""Slotted placement of a per-block stream (hf_encode_chunks_slotted / hf_decode_chunks_slotted)
+"""Slotted placement of a per-block stream (hf_encode_chunks_slotted / hf_decode_chunks_slotted) and
+of a stream with one codebook (hf_symbol_stat_fold_dev, hf_encode_slotted / hf_decode_slotted)
 against the oracle's restatement: slot offsets, words per chunk, every payload word including the
 zeroed slot tails, round trips, decode-on-read and the refusals.  The reference has no packer
 (top.scala:60-67 stops at the codebook); the chunk words are those of the dense per-block stream."""
@@ -174,3 +175,100 @@ def test_slotted_empty_input(hf, orc):
     s = sys_.encode_blocks(t, slotted=True)
     assert s.total_words == 0 and int(s.chunk_off[0].item()) == 0
     assert dec.decode(s).numel() == 0
+
+
+@pytest.mark.parametrize("kind,n", [
+    ("geom", 1), ("geom", 16384), ("geom", 16385), ("mixed", 9 * 16384 + 77), ("uniform", 4 * 16384),
+    ("const", 3 * 16384 + 5), ("mixed", 1100 * 16384 + 4097),
+])
+def test_one_codebook_slotted_stream_matches_the_oracle(hf, orc, kind, n):
+    sym = make(kind, n, n % 1000 + 11)
+    t = to_dev(sym)
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    dec = hf.ParrallelHuffmanDecoder(ctx=sys_.ctx)
+    s = sys_.encode(t, mode=hf.HF_MODE_HUFFMAN, slotted=True)
+    # the folded per-chunk counts are the stream's counts, so the codebook is the stream's
+    code, lens, mode, _ = s.codebook.download()
+    ec, el = orc.rp_system_codebook(orc.aw_symbol_stat(sym, 256, 64), 64, 0, 16)
+    assert mode == 1 and np.array_equal(code, ec) and np.array_equal(lens, el)
+    payload, slot_off, words = orc.rp_encode_slotted(sym, ec, el)
+    nch = s.nchunks
+    assert s.total_words == payload.size == int(slot_off[nch])
+    assert np.array_equal(s.chunk_off[: nch + 1].cpu().numpy().view(np.uint32), slot_off)
+    assert np.array_equal(s.chunk_words[:nch].cpu().numpy().view(np.uint32), words)
+    assert np.array_equal(s.payload[: payload.size].cpu().numpy().view(np.uint32), payload)
+    assert torch.equal(dec.decode(s), t)
+    with pytest.raises(ValueError):
+        s.to_container()
+
+
+def test_one_codebook_slotted_bf16_and_sub_fields(hf, orc):
+    n = 41 * 16384 + 321
+    rng = np.random.default_rng(13)
+    w = (rng.standard_normal(n) * 0.02).astype(np.float32)
+    bits = (w.view(np.uint32) >> 16).astype(np.uint16)
+    t = to_dev(bits).view(torch.bfloat16)
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    dec = hf.ParrallelHuffmanDecoder(ctx=sys_.ctx)
+    s = sys_.encode(t, mode=hf.HF_MODE_HUFFMAN, slotted=True)
+    esym, eside = orc.symbolize(bits, orc.LAYOUT_BF16_EXP)
+    ec, el = orc.rp_system_codebook(orc.aw_symbol_stat(esym, 256, 64), 64, 0, 16)
+    payload, slot_off, words = orc.rp_encode_slotted(esym, ec, el)
+    assert s.total_words == payload.size
+    assert np.array_equal(s.payload[: payload.size].cpu().numpy().view(np.uint32), payload)
+    assert np.array_equal(s.side[:n].cpu().numpy(), eside)
+    assert torch.equal(dec.decode(s).view(torch.int16), t.view(torch.int16))
+    # fp8 E4M3 exponent fields in front of the same path
+    b = (rng.standard_normal(n) * 0.3).astype(np.float32)
+    t8 = torch.from_numpy(b).to(DEV).to(torch.float8_e4m3fn)
+    s8 = sys_.encode(t8.view(torch.uint8), layout=hf.HF_LAYOUT_FP8_E4M3_EXP, slotted=True)
+    assert s8.chunk_words is not None
+    assert torch.equal(dec.decode(s8), t8.view(torch.uint8))
+
+
+def test_fold_adds_per_chunk_counts_into_the_streams(hf, orc):
+    n = 700 * 16384 + 99
+    sym = make("mixed", n, 5)
+    t = to_dev(sym)
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    lib, h = hf.L.lib(), sys_.ctx.handle
+    nch = (n + 16383) // 16384
+    fc = torch.empty(nch * 256, dtype=torch.int32, device=DEV)
+    f = torch.full((256,), 7, dtype=torch.int64, device=DEV)  # fold ADDS
+    P = lambda x: C.c_void_p(x.data_ptr())
+    assert lib.hf_symbol_stat_chunks_dev(h, P(t), n, 0, P(fc)) == 0
+    assert lib.hf_symbol_stat_fold_dev(h, P(fc), nch, P(f)) == 0
+    sys_.ctx.sync()
+    want = np.bincount(sym, minlength=256).astype(np.int64) + 7
+    assert np.array_equal(f.cpu().numpy(), want)
+    assert lib.hf_symbol_stat_fold_dev(h, None, 0, None) == 0
+    assert lib.hf_symbol_stat_fold_dev(h, None, 3, P(f)) == hf.L.HF_ERR_ARG
+
+
+def test_one_codebook_slotted_refusals(hf, orc):
+    n = 5 * 16384 + 100
+    sym = make("geom", n, 3)
+    t = to_dev(sym)
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    lib, h = hf.L.lib(), sys_.ctx.handle
+    s = sys_.encode(t, mode=hf.HF_MODE_HUFFMAN, slotted=True)
+    P = lambda x: C.c_void_p(x.data_ptr())
+    total = C.c_uint64(0)
+    small = torch.full((s.total_words - 1,), 0x5A5A5A5A, dtype=torch.int32, device=DEV)
+    off = torch.empty(8, dtype=torch.int32, device=DEV)
+    cw = torch.empty(8, dtype=torch.int32, device=DEV)
+    rc = lib.hf_encode_slotted(h, P(t), n, 0, C.c_void_p(s.codebook.ptr), P(s.chunk_freq), None,
+                               P(small), small.numel(), P(off), P(cw), C.byref(total))
+    assert rc == hf.L.HF_ERR_OVERFLOW and bool((small == 0x5A5A5A5A).all())
+    out = torch.empty(n, dtype=torch.uint8, device=DEV)
+    rc = lib.hf_decode_slotted(h, P(s.payload), s.payload.numel(), P(s.chunk_off), None, None, n, 0,
+                               C.c_void_p(s.codebook.ptr), P(out), 1)
+    assert rc == hf.L.HF_ERR_ARG
+    bad = s.chunk_words.clone()
+    bad[1] = int(s.chunk_off[2].item()) - int(s.chunk_off[1].item()) + 1
+    rc = lib.hf_decode_slotted(h, P(s.payload), s.payload.numel(), P(s.chunk_off), P(bad), None, n,
+                               0, C.c_void_p(s.codebook.ptr), P(out), 1)
+    assert rc == hf.L.HF_ERR_CORRUPT
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:16384], sym[:16384]) and np.array_equal(got[2 * 16384:], sym[2 * 16384:])
+    assert torch.equal(hf.ParrallelHuffmanDecoder(ctx=sys_.ctx).decode(s), t)
