@@ -773,11 +773,12 @@ static int encode_slotted_common(hf_ctx* ctx, const void* d_data, uint64_t n, in
         }
         size_t cap = (size_t)1 << 16;  // 8 Mi chunks' worth; doubled until it holds this call
         while (cap < aux) cap *= 2;
-        HF_HIP(hipMalloc(&ctx->d_scan_aux, cap));
+        // (behind the scan's totals: the dump area for words of a chunk that outgrows its slot)
+        HF_HIP(hipMalloc(&ctx->d_scan_aux, cap + hf_slot_dump_bytes()));
         ctx->scan_aux_bytes = cap;
     }
-    if (nchunks && !ctx->d_spill)
-        HF_HIP(hipMalloc(&ctx->d_spill, hf_encode_spill_bytes(ctx->num_cu)));
+    uint32_t* const dump = reinterpret_cast<uint32_t*>(
+        reinterpret_cast<unsigned char*>(ctx->d_scan_aux) + ctx->scan_aux_bytes);
     if (nchunks == 0) {
         zero_words(d_chunk_off, 1, ctx->stream);
     } else {
@@ -789,7 +790,7 @@ static int encode_slotted_common(hf_ctx* ctx, const void* d_data, uint64_t n, in
                                         reinterpret_cast<const uint32_t*>(d_codebook),
                                         per_chunk ? (uint32_t)(sizeof(hf_chunk_cb) / 4) : 0u,
                                         d_freq_chunks, d_side, d_payload, payload_cap_words,
-                                        d_chunk_off, d_chunk_words, ctx->d_scan_aux, ctx->d_spill,
+                                        d_chunk_off, d_chunk_words, ctx->d_scan_aux, dump,
                                         ctx->d_ctl + 1, ctx->num_cu, ctx->stream);
         const hipError_t launch_err = hipGetLastError();
         toc(ctx);

@@ -116,6 +116,7 @@ void hf_launch_encode(const void* d_data, uint64_t n, int layout, const hf_cb_de
                       uint32_t* d_spill, uint32_t* d_err, int num_cu, hipStream_t s);
 size_t hf_encode_spill_bytes(int num_cu);
 size_t hf_scan_aux_bytes(uint64_t m);
+size_t hf_slot_dump_bytes();
 void hf_launch_encode_chunks_slotted(const void* d_data, uint64_t n, int layout,
                                      const uint32_t* d_enc, uint32_t enc_stride,
                                      const uint32_t* d_freq_chunks,

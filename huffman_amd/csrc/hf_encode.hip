@@ -776,6 +776,9 @@ __global__ __launch_bounds__(256) void hf_k_encode_slotted(
 
 }  // namespace
 
+// (what hf_k_encode_slotted may write behind `dump`: one chunk's largest size)
+size_t hf_slot_dump_bytes() { return (size_t)kMaxChunkWords * sizeof(uint32_t); }
+
 size_t hf_scan_aux_bytes(uint64_t m) {
     // (one total per group of the scan, and the grand total behind them)
     return (size_t)((m + kScanPerGroup - 1) / kScanPerGroup + 1) * sizeof(u64);
@@ -790,7 +793,6 @@ void hf_launch_encode_chunks_slotted(const void* d_data, uint64_t n, int layout,
                                      uint32_t* d_slot_off, uint32_t* d_chunk_words,
                                      unsigned long long* d_scan_aux, uint32_t* d_dump,
                                      uint32_t* d_err, int num_cu, hipStream_t s) {
-    static_assert(2 * kSpillWords >= kMaxChunkWords, "the dump area is the v1 encoder's spill area");
     const uint64_t nchunks = (n + HF_CHUNK_SYMS - 1) / HF_CHUNK_SYMS;
     if (nchunks == 0) return;
     const uint64_t m = nchunks + 1;

@@ -226,6 +226,24 @@ def test_one_codebook_slotted_bf16_and_sub_fields(hf, orc):
     assert torch.equal(dec.decode(s8), t8.view(torch.uint8))
 
 
+@pytest.mark.parametrize("mode", ["bypass", "auto", "best"])
+def test_one_codebook_slotted_other_modes(hf, orc, mode):
+    n = 6 * 16384 + 1000
+    sym = make("uniform" if mode != "best" else "geom", n, 31)
+    t = to_dev(sym)
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    m = {"bypass": hf.HF_MODE_BYPASS, "auto": hf.HF_MODE_AUTO, "best": hf.HF_MODE_BEST}[mode]
+    s = sys_.encode(t, mode=m, slotted=True)
+    code, lens, got_mode, _ = s.codebook.download()
+    payload, slot_off, words = orc.rp_encode_slotted(sym, code, lens)
+    if mode == "bypass":
+        assert got_mode == 0 and (lens == 8).all()
+    assert s.total_words == payload.size
+    assert np.array_equal(s.payload[: payload.size].cpu().numpy().view(np.uint32), payload)
+    assert np.array_equal(s.chunk_words[: s.nchunks].cpu().numpy().view(np.uint32), words)
+    assert torch.equal(hf.ParrallelHuffmanDecoder(ctx=sys_.ctx).decode(s), t)
+
+
 def test_fold_adds_per_chunk_counts_into_the_streams(hf, orc):
     n = 700 * 16384 + 99
     sym = make("mixed", n, 5)
