@@ -606,11 +606,12 @@ hf_k_encode(const void* __restrict__ data, const uint64_t n, const uint32_t nchu
 // lengths, which the per-chunk histogram and the chunk's codebook give without reading the data
 // (a lane asks for a word only while it holds fewer than 32 bits, so it ends with at most 62
 // unread ones and takes at most floor((T + 62) / 32) words for the T bits of its codes; 64 lanes
-// take at most floor(B_c / 32) + 124: no chunk needs more).  Slot offsets are a prefix sum of the slot sizes.  With the place known, words go
-// straight to global memory as they complete: no staging in LDS, no tile descriptors, no look-back,
-// no scout, and a wavefront needs 1 KiB of LDS for its table instead of 17 KiB -- occupancy is
-// bounded by registers, not LDS, and the per-wavefront latency of the symbol loop is covered by
-// the other wavefronts.  What a slot has left over is zeroed.
+// take at most floor(B_c / 32) + 124: no chunk needs more).  Slot offsets are a prefix sum of the
+// slot sizes.  With the place known, words go straight to global memory as they complete: no
+// staging in LDS, no tile descriptors, no look-back, no scout, and a wavefront needs 1 KiB of LDS
+// for its table instead of 17 KiB -- occupancy is bounded by registers, not LDS, and the
+// per-wavefront latency of the symbol loop is covered by the other wavefronts.  What a slot has
+// left over is zeroed.
 
 // slot size of every chunk into slot[c]; slot[nchunks] = 0 (the scan turns it into the total).
 // enc: the code table (code | len << 16 by symbol) of chunk 0; chunk c's lies enc_stride words
@@ -630,8 +631,12 @@ __global__ __launch_bounds__(256) void hf_k_slot_sizes(const uint32_t* __restric
     const uint4 f = reinterpret_cast<const uint4*>(freq_chunks + (size_t)c * 256)[lane];
     const uint4 e = reinterpret_cast<const uint4*>(enc + (size_t)c * enc_stride)[lane];
     uint32_t bits = f.x * (e.x >> 16) + f.y * (e.y >> 16) + f.z * (e.z >> 16) + f.w * (e.w >> 16);
-    bits = hf_wave_sum_u32(bits);  // <= 16384 * 16
-    if (lane == 0) slot[c] = HF_SLOT_WORDS(bits);
+    bits = hf_wave_sum_u32(bits);
+    // A chunk's own counts give at most 16384 * 16.  Counts from elsewhere may give anything (the
+    // sum may even have wrapped): clamped, every slot stays below 8320 words, the 32-bit sums of
+    // the scan cannot wrap, and the encoder finds the chunk too large for its slot.
+    const uint32_t most = HF_CHUNK_SYMS * (uint32_t)HF_MAX_CODE_LEN;
+    if (lane == 0) slot[c] = HF_SLOT_WORDS(bits < most ? bits : most);
 }
 
 // In-place exclusive prefix sum of m 32-bit values, three kernels: 1024 values per workgroup with
@@ -736,7 +741,12 @@ __global__ __launch_bounds__(256) void hf_k_encode_slotted(
         const void* chunk_in = reinterpret_cast<const uint8_t*>(data) + first * elem_bytes;
         uint8_t* side_chunk = side ? side + first : nullptr;
         const uint32_t off0 = __builtin_amdgcn_readfirstlane(slot_off[c]);
-        const uint32_t slot = __builtin_amdgcn_readfirstlane(slot_off[c + 1]) - off0;
+        const uint32_t off_next = __builtin_amdgcn_readfirstlane(slot_off[c + 1]);
+        if (off_next < off0 || (u64)off_next > limit) {  // (never with offsets of the scan above)
+            if (lane == 0) atomicOr(err, HF_KERR_CORRUPT);
+            continue;
+        }
+        const uint32_t slot = off_next - off0;
         if (enc_stride != 0 || !have_table) {  // (a stream-wide table is fetched once)
             const uint32_t* src = enc_src + (size_t)c * enc_stride;
 #pragma unroll

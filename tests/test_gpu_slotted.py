@@ -150,6 +150,15 @@ def test_slotted_refusals(hf, orc):
     if int(lens[rare]) * 16384 > int(s.chunk_words[0].item()) * 32 + 126 * 32:
         assert rc == hf.L.HF_ERR_CORRUPT
     assert bool((buf[cap:] == 0x5A5A5A5A).all())
+    # counts that are nobody's (sums that wrap 32 bits, zeros): every slot is clamped or too small,
+    # the call reports it and stays inside the buffer
+    for fill in (0x7FFFFFFF, 0):
+        wild = torch.full_like(s.chunk_freq, fill)
+        buf.fill_(0x5A5A5A5A)
+        rc = lib.hf_encode_chunks_slotted(h, P(t), n, 0, P(s.chunk_codebooks), P(wild), None,
+                                          P(buf), cap, P(off), P(cw), C.byref(total))
+        assert rc in (hf.L.HF_ERR_CORRUPT, hf.L.HF_ERR_OVERFLOW)
+        assert bool((buf[cap:] == 0x5A5A5A5A).all())
     # a stream without its words array, a chunk whose words pass its slot
     out = torch.empty(n, dtype=torch.uint8, device=DEV)
     rc = lib.hf_decode_chunks_slotted(h, P(s.payload), s.payload.numel(), P(s.chunk_off), None,
