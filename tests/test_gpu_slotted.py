@@ -177,6 +177,14 @@ def test_slotted_refusals(hf, orc):
     assert s2.total_words == s.total_words
 
 
+def test_one_codebook_slotted_empty_input(hf, orc):
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    t = torch.empty(0, dtype=torch.uint8, device=DEV)
+    s = sys_.encode(t, slotted=True)
+    assert s.total_words == 0 and int(s.chunk_off[0].item()) == 0
+    assert hf.ParrallelHuffmanDecoder(ctx=sys_.ctx).decode(s).numel() == 0
+
+
 def test_slotted_empty_input(hf, orc):
     sys_ = hf.EntropyAwareHuffmanSystem()
     dec = hf.ParrallelHuffmanDecoder(ctx=sys_.ctx)
