@@ -60,7 +60,6 @@ def config1(args):
     ctx = hf.Context(0)
     system = hf.EntropyAwareHuffmanSystem(ctx=ctx)
     decoder = hf.ParrallelHuffmanDecoder(ctx=ctx)
-    stat = hf.SymbolStat(ctx=ctx)
     freq = torch.zeros(256, dtype=torch.int64, device=dev)
     cb = hf.DeviceCodebook(ctx)
     payload = torch.empty(n // 4 + 192 + 64, dtype=torch.int32, device=dev)
@@ -68,16 +67,15 @@ def config1(args):
     out = torch.empty(n, dtype=torch.uint8, device=dev)
 
     def block(ev=None):
+        # SymbolStat and the codebook in one launch (hf_system_codebook_block_dev), then the packer
+        # and the decoder: three calls per block
         if ev: ev[0].record()
-        freq.zero_()
-        stat.accumulate(t, freq)
+        system.codebook_of_block(t, hf.HF_MODE_HUFFMAN, freq256=freq, out=cb)
         if ev: ev[1].record()
-        system.codebook(freq, hf.HF_MODE_HUFFMAN, out=cb)
-        if ev: ev[2].record()
         s = system.encode_with(t, cb, payload=payload, chunk_off=off, sync=False)
-        if ev: ev[3].record()
+        if ev: ev[2].record()
         decoder.decode(s, out=out, check_stream=False)
-        if ev: ev[4].record()
+        if ev: ev[3].record()
         return s
 
     for _ in range(max(args.warmup, 3)):
@@ -92,11 +90,12 @@ def config1(args):
         ctx.sync()
         lat.append(time.perf_counter() - t0)
     # device time per phase
-    evs = [_events(torch, 5) for _ in range(steps)]
+    evs = [_events(torch, 4) for _ in range(steps)]
     for k in range(steps):
         block(evs[k])
     torch.cuda.synchronize()
-    ms = _phase_ms(evs, ["hist", "codebook", "encode", "decode"])
+    ms = _phase_ms(evs, ["codebook", "encode", "decode"])
+
     # throughput: blocks issued back to back, one wait at the end
     nb = 512
     torch.cuda.synchronize()
@@ -112,15 +111,12 @@ def config1(args):
     try:
         side = torch.cuda.Stream()
         ctx_g = hf.Context(0, stream=side)
-        sys_g, dec_g, stat_g = (hf.EntropyAwareHuffmanSystem(ctx=ctx_g),
-                                hf.ParrallelHuffmanDecoder(ctx=ctx_g), hf.SymbolStat(ctx=ctx_g))
+        sys_g, dec_g = hf.EntropyAwareHuffmanSystem(ctx=ctx_g), hf.ParrallelHuffmanDecoder(ctx=ctx_g)
         cb_g = hf.DeviceCodebook(ctx_g)
         out_g = torch.empty(n, dtype=torch.uint8, device=dev)
 
         def block_g():
-            freq.zero_()
-            stat_g.accumulate(t, freq)
-            sys_g.codebook(freq, hf.HF_MODE_HUFFMAN, out=cb_g)
+            sys_g.codebook_of_block(t, hf.HF_MODE_HUFFMAN, freq256=freq, out=cb_g)
             sg = sys_g.encode_with(t, cb_g, payload=payload, chunk_off=off, sync=False)
             dec_g.decode(sg, out=out_g, check_stream=False)
 
@@ -177,7 +173,7 @@ def config1(args):
 
     dev_us = sum(ms.values()) * 1e3
     dominant = max(ms, key=ms.get)
-    alg = {"hist": n, "codebook": 2048 + 36864, "encode": n * (1 + lbar / 8) + 4,
+    alg = {"codebook": n + 2048 + 36864, "encode": n * (1 + lbar / 8) + 4,
            "decode": n * (lbar / 8 + 1) + 4}
     line = {
         "metric": bench.METRIC, "value": nb * n / batched / 1e9, "unit": "GB/s", "n_gpus": 1,
@@ -186,7 +182,7 @@ def config1(args):
         "data": "synthetic",
         "config": {"workload": "config 1: one 4 KB block, 4096 symbols uniform over 0..255 "
                                "(seed 1), 256-symbol alphabet, Huffman forced, Lmax=16; "
-                               "histogram -> codebook -> encode -> decode per block",
+                               "histogram + codebook (one launch) -> encode -> decode per block",
                    "block_symbols": n},
         "us_per_block_latency_host": 1e6 * sorted(lat)[len(lat) // 2],
         "us_per_block_device": dev_us,

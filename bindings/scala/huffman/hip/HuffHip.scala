@@ -54,6 +54,9 @@ trait HuffHip extends Library {
   // EntropyAwareTreeBuilder.io (entropy_aware_tree_builder.scala:7-19)
   def hf_codebook(ctx: Pointer, hFreq: Array[Long], depth: Int, cfg: EntropyConfig,
                   hCode: Array[Short], hLen: Array[Byte]): Int
+  // the same from one block of at most 65536 symbols, counted in the same launch
+  def hf_system_codebook_block_dev(ctx: Pointer, dData: Pointer, n: Long, layout: Int, mode: Int,
+                                   minFreq: Long, dFreq256: Pointer, dCodebook: Pointer): Int
   def hf_system_codebook_dev(ctx: Pointer, dFreq256: Pointer, mode: Int, minFreq: Long,
                              dCodebook: Pointer): Int
   // MemWrapper.io (mem_wrapper.scala:7-26)

@@ -22,6 +22,7 @@ HF_LAYOUT_FP16_EXP, HF_LAYOUT_FP8_E4M3_EXP = 3, 4
 HF_LAYOUT_FP4_E2M1_EXP, HF_LAYOUT_BITPLANE8 = 5, 6
 HF_BITPLANE_BLOCK = 131072
 HF_CHUNK_SYMS = 16384
+HF_BLOCK_MAX_SYMS = 65536
 HF_MAX_CODE_LEN = 16
 HF_MODE_BYPASS, HF_MODE_HUFFMAN, HF_MODE_AUTO, HF_MODE_BEST = 0, 1, 2, 3
 HF_CODEBOOK_DEV_BYTES = 36864
@@ -96,6 +97,8 @@ SIGNATURES = {
     "hf_tree_adjust": (C.c_int, [_vp, _u16p, C.c_int, C.c_int, _u16p]),
     "hf_codebook": (C.c_int, [_vp, _u64p, C.c_int, C.POINTER(hf_entropy_config), _u16p, _u8p]),
     "hf_system_codebook_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_uint64, _vp]),
+    "hf_system_codebook_block_dev": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_uint64,
+                                               _vp, _vp]),
     "hf_codebook_upload": (C.c_int, [_vp, _u16p, _u8p, C.c_int, _vp]),
     "hf_codebook_download": (C.c_int, [_vp, _vp, _u16p, _u8p, _ip, _u32p]),
     "hf_encode_pairs": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, _vp, _vp]),

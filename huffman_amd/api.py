@@ -510,6 +510,23 @@ class EntropyAwareHuffmanSystem(_Module):
               "hf_system_codebook_dev")
         return cb
 
+    def codebook_of_block(self, data_in: torch.Tensor, mode: int = HF_MODE_AUTO,
+                          min_freq_threshold: int = 0, layout: Optional[int] = None,
+                          freq256: Optional[torch.Tensor] = None,
+                          out: Optional[DeviceCodebook] = None):
+        """``hf_system_codebook_block_dev``: SymbolStat and the codebook of one block of at most
+        HF_BLOCK_MAX_SYMS symbols in one launch.  Returns (codebook, counts int64[256])."""
+        lay = layout_of(data_in) if layout is None else layout
+        data_in = data_in.contiguous()
+        cb = out if out is not None else DeviceCodebook(self.ctx)
+        if freq256 is None:
+            freq256 = torch.empty(256, dtype=torch.int64, device=data_in.device)
+        check(L.lib().hf_system_codebook_block_dev(
+            self.ctx.handle, C.c_void_p(_dev_ptr(data_in)), data_in.numel(), lay, mode,
+            min_freq_threshold, C.c_void_p(freq256.data_ptr()), C.c_void_p(cb.ptr)),
+            "hf_system_codebook_block_dev")
+        return cb, freq256
+
     def encode_with(self, data_in: torch.Tensor, cb: DeviceCodebook, layout: Optional[int] = None,
                     payload: Optional[torch.Tensor] = None, side: Optional[torch.Tensor] = None,
                     chunk_off: Optional[torch.Tensor] = None, sync: bool = True) -> EncodedStream:
@@ -579,6 +596,9 @@ class EntropyAwareHuffmanSystem(_Module):
             return s
         if slotted:
             return self._encode_slotted(data_in, mode, layout, min_freq_threshold)
+        if data_in.numel() <= L.HF_BLOCK_MAX_SYMS:  # one block: counted where the codebook is built
+            cb, _ = self.codebook_of_block(data_in, mode, min_freq_threshold, layout)
+            return self.encode_with(data_in, cb, layout)
         freq = self.histogram(data_in, layout)
         cb = self.codebook(freq, mode, min_freq_threshold)
         return self.encode_with(data_in, cb, layout)

@@ -480,6 +480,27 @@ int hf_system_codebook_dev(hf_ctx* ctx, const uint64_t* d_freq256, int mode,
     return HF_OK;
 }
 
+int hf_system_codebook_block_dev(hf_ctx* ctx, const void* d_data, uint64_t n, int layout, int mode,
+                                 uint64_t min_freq_threshold, uint64_t* d_freq256,
+                                 void* d_codebook) {
+    if (!ctx || !d_freq256 || !d_codebook || !layout_ok(layout) || (n && !d_data))
+        return HF_ERR_ARG;
+    if (mode != HF_MODE_BYPASS && mode != HF_MODE_HUFFMAN && mode != HF_MODE_AUTO &&
+        mode != HF_MODE_BEST)
+        return HF_ERR_ARG;
+    if (!aligned16(d_data) || !aligned16(d_freq256) || !aligned16(d_codebook)) return HF_ERR_ALIGN;
+    if (n > HF_BLOCK_MAX_SYMS) return HF_ERR_RANGE;
+    HF_USE_DEVICE(ctx);
+    tic(ctx);
+    hf_launch_system_block(d_data, (uint32_t)n, norm_layout(layout), mode, min_freq_threshold,
+                           reinterpret_cast<unsigned long long*>(d_freq256),
+                           reinterpret_cast<hf_cb_dev*>(d_codebook), ctx->stream);
+    const hipError_t launch_err = hipGetLastError();
+    toc(ctx);
+    HF_HIP(launch_err);
+    return HF_OK;
+}
+
 /* ---- MemWrapper ---------------------------------------------------------------------------------- */
 int hf_codebook_upload(hf_ctx* ctx, const uint16_t* h_code, const uint8_t* h_len, int mode,
                        void* d_codebook) {

@@ -746,13 +746,50 @@ __global__ __launch_bounds__(256) void hf_k_tables(hf_cb_dev* cb) {
 // One workgroup of four wavefronts: the first builds the codebook (a chain of wave-wide steps)
 // while the others wait at the barrier, then all four build the decode tables from the encoder
 // table left in LDS -- one launch, and the tables never make a trip through global memory.
-__global__ __launch_bounds__(256) void hf_k_system(const u64* __restrict__ freq256,
-                                                   const int mode_req, const u64 thr,
-                                                   hf_cb_dev* cb) {
+//
+// FROM_DATA: the counts are not given but taken from one block of at most HF_BLOCK_MAX_SYMS symbols
+// first (SymbolStat in front of the rest, as in top_encoder.scala:29-41): counted in LDS by all
+// four wavefronts and left in `freq_out`, from where the codebook is built as from given counts.
+template <bool FROM_DATA>
+__global__ __launch_bounds__(256) void hf_k_system(const u64* freq_in, const int mode_req,
+                                                   const u64 thr, hf_cb_dev* cb, const void* data,
+                                                   const uint32_t n, const int layout,
+                                                   u64* freq_out) {
     __shared__ CbLds L;
     __shared__ u64 sorted[256];
     __shared__ TabLds T;
     const int N = 256;
+    const u64* freq256 = freq_in;
+    if (FROM_DATA) {
+        __shared__ uint32_t block_counts[256];
+        block_counts[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t* words = reinterpret_cast<const uint32_t*>(data);  // (16-byte aligned)
+        if (layout == HF_LAYOUT_BF16_EXP) {  // symbol = bits 7..14 of a 16-bit element
+            for (uint32_t i = threadIdx.x; i < n / 2; i += 256) {
+                const uint32_t w = words[i];
+                atomicAdd(&block_counts[(w >> 7) & 0xFFu], 1u);
+                atomicAdd(&block_counts[(w >> 23) & 0xFFu], 1u);
+            }
+            if ((n & 1u) && threadIdx.x == 0) {
+                const uint32_t e = reinterpret_cast<const uint16_t*>(data)[n - 1];
+                atomicAdd(&block_counts[(e >> 7) & 0xFFu], 1u);
+            }
+        } else {
+            for (uint32_t i = threadIdx.x; i < n / 4; i += 256) {
+                const uint32_t w = words[i];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) atomicAdd(&block_counts[(w >> (8 * k)) & 0xFFu], 1u);
+            }
+            if (threadIdx.x < (n & 3u))
+                atomicAdd(&block_counts[reinterpret_cast<const uint8_t*>(data)[(n & ~3u) + threadIdx.x]],
+                          1u);
+        }
+        __syncthreads();
+        freq_out[threadIdx.x] = block_counts[threadIdx.x];
+        __syncthreads();  // (the workgroup's global stores are visible to its later loads)
+        freq256 = freq_out;
+    }
     if (threadIdx.x < 64) {  // (wave-uniform)
         const int lane = hf_lane();
         stage_sort(freq256, N, sorted, L.rank2sym, lane);
@@ -1221,7 +1258,16 @@ void hf_launch_stage(hf_stage_io* io, int N, int op, int lmax, unsigned long lon
 
 void hf_launch_system(const unsigned long long* d_freq256, int mode, unsigned long long thr,
                       hf_cb_dev* cb, hipStream_t s) {
-    hipLaunchKernelGGL(hf_k_system, dim3(1), dim3(256), 0, s, d_freq256, mode, thr, cb);
+    hipLaunchKernelGGL(hf_k_system<false>, dim3(1), dim3(256), 0, s, d_freq256, mode, thr, cb,
+                       (const void*)nullptr, 0u, 0, (unsigned long long*)nullptr);
+}
+
+void hf_launch_system_block(const void* d_data, uint32_t n, int layout, int mode,
+                            unsigned long long thr, unsigned long long* d_freq256, hf_cb_dev* cb,
+                            hipStream_t s) {
+    hipLaunchKernelGGL(hf_k_system<true>, dim3(1), dim3(256), 0, s,
+                       (const unsigned long long*)nullptr, mode, thr, cb, d_data, n, layout,
+                       d_freq256);
 }
 
 static_assert(HF_CB_SCRATCH_PER_CHUNK == 256 + 512 + 256 + 16, "scratch layout (carve_scratch)");

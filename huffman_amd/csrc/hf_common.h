@@ -124,6 +124,9 @@ void hf_launch_encode_chunks_slotted(const void* d_data, uint64_t n, int layout,
                                      uint32_t* d_slot_off, uint32_t* d_chunk_words,
                                      unsigned long long* d_scan_aux, uint32_t* d_dump,
                                      uint32_t* d_err, int num_cu, hipStream_t s);
+void hf_launch_system_block(const void* d_data, uint32_t n, int layout, int mode,
+                            unsigned long long thr, unsigned long long* d_freq256, hf_cb_dev* cb,
+                            hipStream_t s);
 void hf_launch_fold_chunks(const uint32_t* d_freq_chunks, uint64_t nchunks,
                            unsigned long long* d_freq256, hipStream_t s);
 void hf_launch_hist_chunks(const void* d_data, uint64_t n, int layout, uint32_t* d_freq_chunks,

@@ -197,6 +197,17 @@ int hf_codebook(hf_ctx* ctx, const uint64_t* h_freq, int N, const hf_entropy_con
 int hf_system_codebook_dev(hf_ctx* ctx, const uint64_t* d_freq256, int mode,
                            uint64_t min_freq_threshold, void* d_codebook);
 
+/* The same front half fed with ONE block of symbols instead of its counts, in one launch
+ * (top_encoder.scala:29-41 puts SymbolStat in front of the sort in the same module): counts the
+ * n <= HF_BLOCK_MAX_SYMS elements at d_data, leaves the counts in d_freq256 (overwritten, not
+ * added to) and builds the codebook from them.  For small blocks the two launches of
+ * hf_symbol_stat_dev + hf_system_codebook_dev cost more than the work; larger inputs take those.
+ * No synchronisation. */
+#define HF_BLOCK_MAX_SYMS 65536u
+int hf_system_codebook_block_dev(hf_ctx* ctx, const void* d_data, uint64_t n, int layout, int mode,
+                                 uint64_t min_freq_threshold, uint64_t* d_freq256,
+                                 void* d_codebook);
+
 /* ---- MemWrapper (mem_wrapper.scala:6-87): the codebook store ------------------------------- */
 /* write port, all entries: build a device codebook from host tables indexed by symbol. */
 int hf_codebook_upload(hf_ctx* ctx, const uint16_t* h_code, const uint8_t* h_len, int mode,

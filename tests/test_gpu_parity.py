@@ -232,6 +232,41 @@ def system_roundtrip(hf, orc, data_t, sym, mode=1, side=None):
     return s
 
 
+@pytest.mark.parametrize("n", [0, 1, 3, 5, 4096, 16385, 65535, 65536])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_block_codebook_in_one_launch(hf, orc, n, bf16):
+    # SymbolStat + the system codebook of one block (hf_system_codebook_block_dev) against the
+    # oracle and against the two separate calls
+    import ctypes as C
+    if bf16:
+        w = gaussian_bf16(max(n, 1), seed=n + 3)[:n]
+        sym, _ = orc.symbolize(w, orc.LAYOUT_BF16_EXP) if n else (np.zeros(0, np.uint8), None)
+        t = dev_bf16(w) if n else torch.empty(0, dtype=torch.bfloat16, device=DEV)
+    else:
+        sym = skewed_symbols(max(n, 1), n + 1, "geometric")[:n]
+        t = dev_u8(sym) if n else torch.empty(0, dtype=torch.uint8, device=DEV)
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    stale = torch.full((256,), 12345, dtype=torch.int64, device=DEV)  # overwritten, not added to
+    for mode in (hf.HF_MODE_HUFFMAN, hf.HF_MODE_AUTO):
+        cb, freq = sys_.codebook_of_block(t, mode, freq256=stale)
+        want = orc.aw_symbol_stat(sym, 256, 64)
+        assert np.array_equal(freq.cpu().numpy().astype(np.uint64), want)
+        code, lens, m, ent = cb.download()
+        two = sys_.codebook(sys_.histogram(t), mode)
+        c2, l2, m2, e2 = two.download()
+        assert (m, ent) == (m2, e2) and np.array_equal(code, c2) and np.array_equal(lens, l2)
+        assert ent == orc.rp_entropy_q16_u64(want)
+        if m == 1:
+            ec, el = orc.rp_system_codebook(want, 64, 0, 16)
+            assert np.array_equal(code, ec) and np.array_equal(lens, el)
+    if n == 65536:
+        big = torch.zeros(65552, dtype=torch.uint8, device=DEV)
+        rc = hf.L.lib().hf_system_codebook_block_dev(
+            sys_.ctx.handle, C.c_void_p(big.data_ptr()), 65537, 0, 1, 0,
+            C.c_void_p(stale.data_ptr()), C.c_void_p(cb.ptr))
+        assert rc == hf.L.HF_ERR_RANGE
+
+
 def test_config1_4k_uniform(hf, orc):
     # 4096 symbols, uniform over 0..255, seed 1, Huffman forced
     sym = np.random.default_rng(1).integers(0, 256, 4096, dtype=np.uint8)
