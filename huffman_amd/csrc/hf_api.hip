@@ -597,9 +597,11 @@ static int encode_common(hf_ctx* ctx, const void* d_data, uint64_t n, int layout
     if (nchunks == 0) {
         zero_words(d_chunk_off, 1, ctx->stream);
     } else {
-        // the ticket and the tile descriptors (the error word in d_ctl is sticky and stays)
-        zero_words(reinterpret_cast<uint32_t*>(ctx->d_desc), (2 + ((nchunks + 1) & ~1ull)) * 2,
-                   ctx->stream);
+        // the ticket and the tile descriptors (the error word in d_ctl is sticky and stays); a
+        // stream of a single tile uses neither, and a small block is spared the launch
+        if (!hf_encode_single_tile(nchunks))
+            zero_words(reinterpret_cast<uint32_t*>(ctx->d_desc), (2 + ((nchunks + 1) & ~1ull)) * 2,
+                       ctx->stream);
         unsigned long long* const desc = ctx->d_desc + 2;
         uint32_t* const ticket = reinterpret_cast<uint32_t*>(ctx->d_desc);
         tic(ctx);

@@ -115,6 +115,7 @@ void hf_launch_encode(const void* d_data, uint64_t n, int layout, const hf_cb_de
                       uint32_t* d_chunk_off, unsigned long long* d_desc, uint32_t* d_ticket,
                       uint32_t* d_spill, uint32_t* d_err, int num_cu, hipStream_t s);
 size_t hf_encode_spill_bytes(int num_cu);
+bool hf_encode_single_tile(uint64_t nchunks);
 size_t hf_scan_aux_bytes(uint64_t m);
 size_t hf_slot_dump_bytes();
 void hf_launch_encode_chunks_slotted(const void* d_data, uint64_t n, int layout,

@@ -464,7 +464,9 @@ hf_k_encode(const void* __restrict__ data, const uint64_t n, const uint32_t nchu
     bool pending = false;
     uint32_t p_t = 0, p_total = 0, p_iter = 0;
     for (uint32_t i = 0;; ++i) {
-        if (threadIdx.x == 0) L.ticket = atomicAdd(ticket, 1u);
+        // (no ticket: the stream is one tile and this its only workgroup -- tile 0, then none.
+        // Tile 0 looks back at nothing, so what the descriptors hold does not matter either.)
+        if (threadIdx.x == 0) L.ticket = ticket ? atomicAdd(ticket, 1u) : i;
         __syncthreads();  // ticket visible; the copy-out of the previous iteration is complete
         const uint32_t t = L.ticket;
         const bool live = (uint64_t)t * kWaves < nchunks;
@@ -830,6 +832,10 @@ void hf_launch_encode_chunks_slotted(const void* d_data, uint64_t n, int layout,
                            d_slot_off, d_chunk_words, d_dump, d_total, limit, d_err);
 }
 
+// A stream of one tile needs neither the ticket nor cleared descriptors: the caller may skip
+// clearing them.
+bool hf_encode_single_tile(uint64_t nchunks) { return nchunks <= (uint64_t)kWaves; }
+
 size_t hf_encode_spill_bytes(int num_cu) {
     return (size_t)num_cu * 2 * kWaves * 2 * kSpillWords * sizeof(uint32_t);
 }
@@ -845,6 +851,7 @@ static void launch_encode_impl(const void* d_data, uint64_t n, int layout, const
     uint64_t grid = (nchunks + kWaves - 1) / kWaves;
     const uint64_t cap = (uint64_t)num_cu * 2;  // two ~70 KiB workgroups fit one CU's LDS
     if (grid > cap) grid = cap;
+    if (hf_encode_single_tile(nchunks)) d_ticket = nullptr;  // (grid == 1)
     const size_t lds = sizeof(EncLds<PER_CHUNK>);
     // more than 64 KiB of dynamic LDS has to be allowed per kernel and per device: done on a
     // kernel's first launch on a device (one bit per device; repeating it is harmless, so two
