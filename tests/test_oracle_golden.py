@@ -341,3 +341,29 @@ def test_slotted_placement_keeps_every_chunk_inside_its_slot(orc):
             assert np.array_equal(payload[a:a + int(words[c])], dense[off[c]:off[c + 1]])
             assert not payload[a + int(words[c]):a + slot].any()
         assert payload.size == int(slot_off[nch])
+
+
+def test_slotted_placement_with_one_codebook(orc):
+    rng = np.random.default_rng(78)
+    ch = 16384
+    sym = np.concatenate([np.minimum(rng.geometric(p, ch) - 1, 255) for p in (0.6, 0.05, 0.2)]
+                         + [rng.integers(0, 256, 777)]).astype(np.uint8)
+    code, lens = orc.rp_system_codebook(orc.aw_symbol_stat(sym, 256, 64), 64, 0, 16)
+    payload, slot_off, words = orc.rp_encode_slotted(sym, code, lens)
+    dense, off = orc.rp_encode(sym, code, lens)
+    nch = orc.num_chunks(sym.size)
+    assert np.array_equal(np.diff(off.astype(np.int64)), words.astype(np.int64))
+    for c in range(nch):
+        part = sym[c * ch:(c + 1) * ch]
+        bits = int(lens[part].astype(np.int64).sum())
+        slot = int(slot_off[c + 1]) - int(slot_off[c])
+        assert slot == orc.slot_words(bits) and int(words[c]) <= bits // 32 + 124
+        a = int(slot_off[c])
+        assert np.array_equal(payload[a:a + int(words[c])], dense[off[c]:off[c + 1]])
+        assert not payload[a + int(words[c]):a + slot].any()
+    # the chunks decode from their slots as from the dense stream
+    back = np.concatenate([
+        orc.rp_decode(payload[int(slot_off[c]):int(slot_off[c]) + int(words[c])],
+                      np.array([0, words[c]], np.uint32), min(ch, sym.size - c * ch), code, lens)
+        for c in range(nch)])
+    assert np.array_equal(back, sym)
