@@ -596,7 +596,9 @@ class EntropyAwareHuffmanSystem(_Module):
             return s
         if slotted:
             return self._encode_slotted(data_in, mode, layout, min_freq_threshold)
-        if data_in.numel() <= L.HF_BLOCK_MAX_SYMS:  # one block: counted where the codebook is built
+        # one chunk: counted where the codebook is built (larger blocks may still ask for it, but a
+        # block of one repeated symbol serialises the single counter array: kept to one chunk here)
+        if data_in.numel() <= HF_CHUNK_SYMS:
             cb, _ = self.codebook_of_block(data_in, mode, min_freq_threshold, layout)
             return self.encode_with(data_in, cb, layout)
         freq = self.histogram(data_in, layout)
