@@ -22,6 +22,9 @@ trait HuffHip extends Library {
   def hf_sync(ctx: Pointer): Int     // wait for the stream; returns and clears kept kernel errors
   def hf_error_string(code: Int): String
   def hf_last_hip_error(ctx: Pointer): Int
+  // make the context's lazily sized workspaces now (Reserve.ENCODE | CODEBOOKS | PLACED), for
+  // streams of up to maxN elements: later enqueue-only calls allocate and synchronise nothing
+  def hf_ctx_reserve(ctx: Pointer, maxN: Long, flags: Int): Int
   def hf_num_chunks(n: Long): Long
   def hf_payload_bound_words(n: Long): Long                         // worst case over all codebooks
   def hf_set_timing(ctx: Pointer, enabled: Int): Int
@@ -116,6 +119,19 @@ trait HuffHip extends Library {
   def hf_decode_slotted(ctx: Pointer, dPayload: Pointer, payloadWords: Long, dChunkOff: Pointer,
                         dChunkWords: Pointer, dSide: Pointer, n: Long, layout: Int,
                         dCodebook: Pointer, dOut: Pointer, check: Int): Int
+  // paged stream (format version 2): every page carries its codebook record and its exact size
+  // follows from its histogram; four sub-decoders per page (reports/figs/decoder.svg)
+  def hf_pages_bound_words(n: Long): Long
+  def hf_encode_pages(ctx: Pointer, dData: Pointer, n: Long, layout: Int, dChunkCodebooks: Pointer,
+                      dFreqChunks: Pointer, dSide: Pointer, dPayload: Pointer, payloadCapWords: Long,
+                      dPageOff: Pointer, hTotalWords: LongByReference): Int
+  def hf_decode_pages(ctx: Pointer, dPayload: Pointer, payloadWords: Long, dPageOff: Pointer,
+                      dSide: Pointer, n: Long, layout: Int, dPageIds: Pointer, dOutSlots: Pointer,
+                      nIds: Long, dOut: Pointer, nSlots: Long, check: Int): Int
+  def hf_page_codebook_download(ctx: Pointer, dPayload: Pointer, payloadWords: Long,
+                                dPageOff: Pointer, page: Long, hCode: Array[Short],
+                                hLen: Array[Byte], mode: IntByReference,
+                                entropy: IntByReference): Int
   def hf_chunk_codebook_download(ctx: Pointer, dChunkCodebooks: Pointer, chunk: Long,
                                  hCode: Array[Short], hLen: Array[Byte], mode: IntByReference,
                                  entropy: IntByReference): Int
@@ -152,7 +168,10 @@ class EntropyConfig extends Structure {
 
 object HuffHip { lazy val lib: HuffHip = Native.load("huffhip", classOf[HuffHip]) }
 
-// HF_LAYOUT_* and HF_MODE_* of include/huffhip.h
+// HF_RESERVE_*, HF_LAYOUT_* and HF_MODE_* of include/huffhip.h
+object Reserve {
+  val ENCODE = 1; val CODEBOOKS = 2; val PLACED = 4; val ALL = 7
+}
 object Layout {
   val U8 = 0; val BF16_EXP = 1; val FP8 = 2; val FP16_EXP = 3; val FP8_E4M3_EXP = 4
   val FP4_E2M1_EXP = 5; val BITPLANE8 = 6

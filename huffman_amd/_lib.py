@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HUFFHIP_LIB") or os.path.join(_HERE, "lib", "libhuffhip.so")
 
 # ---- constants mirrored from include/huffhip.h ------------------------------------------------
-HF_ABI_VERSION = 2
+HF_ABI_VERSION = 3
 HF_OK = 0
 HF_ERR_ARG, HF_ERR_ALIGN, HF_ERR_RANGE, HF_ERR_HIP = -1, -2, -3, -4
 HF_ERR_OVERFLOW, HF_ERR_TIMEOUT, HF_ERR_CORRUPT, HF_ERR_NOMEM = -5, -6, -7, -8
@@ -32,6 +32,8 @@ HF_CONTAINER_VERSION = 1
 HF_CONTAINER_HEADER_BYTES = 128
 HF_CONTAINER_CHUNK_CODEBOOK_BYTES = 296
 HF_CODEBOOK_STREAM, HF_CODEBOOK_PER_CHUNK = 0, 1
+HF_RESERVE_ENCODE, HF_RESERVE_CODEBOOKS, HF_RESERVE_PLACED, HF_RESERVE_ALL = 1, 2, 4, 7
+HF_PAGE_HDR_WORDS, HF_PAGE_GAP_WORDS = 10, 48
 
 
 def HF_SLOT_WORDS(bits: int) -> int:
@@ -84,6 +86,7 @@ SIGNATURES = {
     "hf_sync": (C.c_int, [_vp]),
     "hf_error_string": (C.c_char_p, [C.c_int]),
     "hf_last_hip_error": (C.c_int, [_vp]),
+    "hf_ctx_reserve": (C.c_int, [_vp, C.c_uint64, C.c_uint]),
     "hf_symbol_stat": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int, _u64p]),
     "hf_symbol_stat_dev": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, _vp]),
     "hf_fields_side_bytes": (C.c_uint64, [C.c_uint64, C.c_int]),
@@ -125,6 +128,13 @@ SIGNATURES = {
                                     _vp, _vp, _u64p]),
     "hf_decode_slotted": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp, C.c_uint64, C.c_int, _vp,
                                     _vp, C.c_int]),
+    "hf_pages_bound_words": (C.c_uint64, [C.c_uint64]),
+    "hf_encode_pages": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, _vp, _vp, _vp, _vp, C.c_uint64, _vp,
+                                  _u64p]),
+    "hf_decode_pages": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, C.c_uint64, C.c_int, _vp, _vp,
+                                  C.c_uint64, _vp, C.c_uint64, C.c_int]),
+    "hf_page_codebook_download": (C.c_int, [_vp, _vp, C.c_uint64, _vp, C.c_uint64, _u16p, _u8p, _ip,
+                                            _u32p]),
     "hf_chunk_codebook_download": (C.c_int, [_vp, _vp, C.c_uint64, _u16p, _u8p, _ip, _u32p]),
     "hf_container_plan": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_uint64,
                                     C.POINTER(hf_container_info)]),

@@ -389,6 +389,9 @@ class EncodedStream:
     # a slotted stream (hf_encode_chunks_slotted): chunk_off are slot starts, and these the words
     # each chunk filled of its slot; None for a dense (format-v1) payload
     chunk_words: Optional[torch.Tensor] = None
+    # a paged stream (hf_encode_pages, format version 2): chunk_off are page offsets, every page
+    # carries its own codebook record, and the decoder needs nothing but payload and offsets
+    paged: bool = False
 
     @property
     def nchunks(self) -> int:
@@ -401,6 +404,8 @@ class EncodedStream:
         counts, mode, entropy).  Section padding and the header are left to container_bytes()."""
         assert self.total_words is not None
         side = side_bytes(self.n, self.layout)
+        if self.paged:  # the records are part of the pages
+            return 4 * self.total_words + side + 4 * (self.nchunks + 1)
         books = 256 * 3 if self.chunk_codebooks is None \
             else L.HF_CONTAINER_CHUNK_CODEBOOK_BYTES * self.nchunks
         index = 4 * (self.nchunks + 1) + (4 * self.nchunks if self.chunk_words is not None else 0)
@@ -413,7 +418,7 @@ class EncodedStream:
     def container_bytes(self) -> int:
         """Size of this stream's container (host arithmetic, nothing is packed)."""
         assert self.total_words is not None, "encode with sync=True first"
-        if self.chunk_words is not None:
+        if self.chunk_words is not None or self.paged:
             raise ValueError("a slotted stream is not a format-v1 payload: no container")
         info = L.hf_container_info()
         check(L.lib().hf_container_plan(self.n, self.layout,
@@ -649,17 +654,22 @@ class EntropyAwareHuffmanSystem(_Module):
     # -- per-block codebooks (one codebook per 16384-symbol chunk, e.g. a KV-cache page) --------
     def encode_blocks(self, data_in: torch.Tensor, mode: int = HF_MODE_AUTO,
                       layout: Optional[int] = None, min_freq_threshold: int = 0,
-                      sync: bool = True, slotted: bool = False) -> EncodedStream:
+                      sync: bool = True, slotted: bool = False,
+                      paged: bool = False) -> EncodedStream:
         """Every chunk is a block of its own: SymbolStat, SymbolSort, the entropy decision and
         EntropyAwareTreeBuilder run once per chunk, then the chunk is packed with its table.
 
         ``slotted``: every chunk goes to a slot sized from its histogram and codebook before the
         encoder runs (``hf_encode_chunks_slotted``): 2-4 % more words, written faster; the stream
-        has ``chunk_words`` beside ``chunk_off`` and no container form."""
+        has ``chunk_words`` beside ``chunk_off`` and no container form.
+
+        ``paged``: the paged stream (``hf_encode_pages``, format version 2): every page carries its
+        codebook record and is sized exactly from its histogram, no look-back and no slack; decoded
+        by ``hf_decode_pages``, four sub-decoders per page."""
         data_in = data_in.contiguous()
         if layout in FIELD_LAYOUTS:
             sym, side = self.split_fields(data_in, layout)
-            s = self.encode_blocks(sym, mode, HF_LAYOUT_U8, min_freq_threshold, sync, slotted)
+            s = self.encode_blocks(sym, mode, HF_LAYOUT_U8, min_freq_threshold, sync, slotted, paged)
             s.layout, s.side, s.dtype = layout, side, data_in.dtype
             return s
         lay = layout_of(data_in) if layout is None else layout
@@ -679,6 +689,26 @@ class EntropyAwareHuffmanSystem(_Module):
         side = torch.empty(max(16, n), dtype=torch.uint8, device=dev) \
             if lay == HF_LAYOUT_BF16_EXP else None
         total = C.c_uint64(0)
+        if paged:
+            def run_pages(buf):
+                return L.lib().hf_encode_pages(
+                    h, C.c_void_p(_dev_ptr(data_in)), n, lay, C.c_void_p(cbs.data_ptr()),
+                    C.c_void_p(freq.data_ptr()), C.c_void_p(_dev_ptr(side)),
+                    C.c_void_p(buf.data_ptr()), buf.numel(), C.c_void_p(chunk_off.data_ptr()),
+                    C.byref(total) if sync else None)
+            # (8 bits per symbol plus a page's record and region lengths; then the worst case)
+            payload = torch.empty(max(16, nch * (HF_CHUNK_SYMS // 4 + 128)), dtype=torch.int32,
+                                  device=dev)
+            rc = run_pages(payload)
+            if rc == L.HF_ERR_OVERFLOW:
+                payload = torch.empty(max(16, int(L.lib().hf_pages_bound_words(n))),
+                                      dtype=torch.int32, device=dev)
+                rc = run_pages(payload)
+            check(rc, "hf_encode_pages")
+            return EncodedStream(n=n, layout=lay, dtype=data_in.dtype, payload=payload,
+                                 chunk_off=chunk_off, side=side, codebook=None,
+                                 total_words=int(total.value) if sync else None,
+                                 chunk_codebooks=cbs, chunk_freq=freq, paged=True)
         if slotted:
             # (slots of the default size hold any block whose codes average <= 8 bits per symbol,
             # i.e. every block unless min_freq_threshold made its codebook from other counts)
@@ -727,6 +757,12 @@ class EntropyAwareHuffmanSystem(_Module):
         lens = np.zeros(256, np.uint8)
         mode = C.c_int(0)
         ent = C.c_uint32(0)
+        if s.paged:  # read back from the page's own record
+            check(L.lib().hf_page_codebook_download(
+                self.ctx.handle, C.c_void_p(s.payload.data_ptr()), s.payload.numel(),
+                C.c_void_p(s.chunk_off.data_ptr()), chunk, _ptr(code, _u16p), _ptr(lens, _u8p),
+                C.byref(mode), C.byref(ent)), "hf_page_codebook_download")
+            return code, lens, int(mode.value), int(ent.value)
         check(L.lib().hf_chunk_codebook_download(self.ctx.handle,
                                                  C.c_void_p(s.chunk_codebooks.data_ptr()), chunk,
                                                  _ptr(code, _u16p), _ptr(lens, _u8p),
@@ -779,7 +815,7 @@ class ParrallelHuffmanDecoder(_Module):  # spelling as in decoder/top_decoder.sc
                       out: Optional[torch.Tensor] = None, check_stream: bool = True) -> torch.Tensor:
         """Decode a stream with per-block codebooks.  With ``chunk_ids`` (int32 device tensor)
         this is decode-on-read: the listed chunks, in that order, land back to back in ``out``."""
-        assert s.chunk_codebooks is not None
+        assert s.chunk_codebooks is not None or s.paged
         if s.layout in FIELD_LAYOUTS:
             if chunk_ids is not None:
                 raise ValueError("decode-on-read of a sub-field stream: decode the symbols with "
@@ -794,6 +830,13 @@ class ParrallelHuffmanDecoder(_Module):  # spelling as in decoder/top_decoder.sc
             n_out = n_ids * HF_CHUNK_SYMS
         if out is None:
             out = torch.empty(max(n_out, 16), dtype=s.dtype, device=s.payload.device)
+        if s.paged:
+            check(L.lib().hf_decode_pages(
+                self.ctx.handle, C.c_void_p(s.payload.data_ptr()), s.payload.numel(),
+                C.c_void_p(s.chunk_off.data_ptr()), C.c_void_p(_dev_ptr(s.side)), s.n, s.layout,
+                C.c_void_p(_dev_ptr(chunk_ids)), None, n_ids, C.c_void_p(_dev_ptr(out)), 0,
+                1 if check_stream else 0), "hf_decode_pages")
+            return out[:n_out]
         if s.chunk_words is not None:
             check(L.lib().hf_decode_chunks_slotted(
                 self.ctx.handle, C.c_void_p(s.payload.data_ptr()), s.payload.numel(),
@@ -816,12 +859,20 @@ class ParrallelHuffmanDecoder(_Module):  # spelling as in decoder/top_decoder.sc
                          page_pool: torch.Tensor, check_stream: bool = True) -> torch.Tensor:
         """Decode-on-read into a paged buffer: chunk ``chunk_ids[k]`` lands in page
         ``out_slots[k]`` of ``page_pool`` (a contiguous tensor of whole 16384-element pages)."""
-        assert s.chunk_codebooks is not None
+        assert s.chunk_codebooks is not None or s.paged
         for t in (chunk_ids, out_slots):
             assert t.dtype == torch.int32 and t.is_cuda and t.is_contiguous()
         assert chunk_ids.numel() == out_slots.numel()
         assert page_pool.is_cuda and page_pool.is_contiguous() and page_pool.dtype == s.dtype
         assert page_pool.numel() % HF_CHUNK_SYMS == 0
+        if s.paged:
+            check(L.lib().hf_decode_pages(
+                self.ctx.handle, C.c_void_p(s.payload.data_ptr()), s.payload.numel(),
+                C.c_void_p(s.chunk_off.data_ptr()), C.c_void_p(_dev_ptr(s.side)), s.n, s.layout,
+                C.c_void_p(chunk_ids.data_ptr()), C.c_void_p(out_slots.data_ptr()),
+                chunk_ids.numel(), C.c_void_p(page_pool.data_ptr()),
+                page_pool.numel() // HF_CHUNK_SYMS, 1 if check_stream else 0), "hf_decode_pages")
+            return page_pool
         if s.chunk_words is not None:
             check(L.lib().hf_decode_chunks_slotted(
                 self.ctx.handle, C.c_void_p(s.payload.data_ptr()), s.payload.numel(),
@@ -845,7 +896,7 @@ class ParrallelHuffmanDecoder(_Module):  # spelling as in decoder/top_decoder.sc
 
     def decode(self, s: EncodedStream, out: Optional[torch.Tensor] = None,
                check_stream: bool = True) -> torch.Tensor:
-        if s.chunk_codebooks is not None:
+        if s.chunk_codebooks is not None or s.paged:
             return self.decode_blocks(s, None, out, check_stream)
         if s.layout in FIELD_LAYOUTS:
             sym = self.decode(self._symbol_view(s), None, check_stream)

@@ -132,6 +132,56 @@ void toc(hf_ctx* ctx) {
     }
 }
 
+// ---- the context's lazily sized workspaces ------------------------------------------------------
+// Each grows on demand: a call that needs more than the context holds synchronises the stream,
+// frees and allocates.  hf_ctx_reserve makes all of them up front, so that later calls within the
+// reserved size only enqueue work (what stream capture and allocation-free loops need).
+
+// tile descriptors of the look-back encoder (two words in front of them hold the tile ticket)
+int ensure_desc(hf_ctx* ctx, uint64_t nchunks) {
+    if (nchunks <= ctx->desc_cap) return HF_OK;
+    // grown geometrically (at least 64 Ki descriptors, 512 KiB), so that a context sees a
+    // handful of allocations over its life, whatever sizes it is asked for
+    if (ctx->d_desc) {
+        HF_HIP(hipStreamSynchronize(ctx->stream));
+        HF_HIP(hipFree(ctx->d_desc));
+        ctx->d_desc = nullptr;
+    }
+    size_t cap = ctx->desc_cap ? ctx->desc_cap * 2 : (size_t)65536;
+    ctx->desc_cap = 0;
+    while (cap < nchunks + 2) cap *= 2;
+    HF_HIP(hipMalloc(&ctx->d_desc, (cap + 2) * sizeof(unsigned long long)));
+    ctx->desc_cap = cap;
+    return HF_OK;
+}
+// spill area of the look-back encoder (~100 MB: two staged chunks per resident wavefront)
+int ensure_spill(hf_ctx* ctx) {
+    if (!ctx->d_spill) HF_HIP(hipMalloc(&ctx->d_spill, hf_encode_spill_bytes(ctx->num_cu)));
+    return HF_OK;
+}
+// batch scratch of the per-block codebook kernels (68 MB)
+int ensure_cbscratch(hf_ctx* ctx) {
+    if (!ctx->d_cbscratch) HF_HIP(hipMalloc(&ctx->d_cbscratch, hf_chunk_cb_scratch_bytes()));
+    return HF_OK;
+}
+// group totals of the offset scan of the slotted and paged encoders, and behind them the dump
+// area for words of a chunk that outgrows its slot
+int ensure_scan_aux(hf_ctx* ctx, uint64_t nchunks) {
+    const size_t aux = hf_scan_aux_bytes(nchunks + 1);
+    if (aux <= ctx->scan_aux_bytes) return HF_OK;
+    if (ctx->d_scan_aux) {
+        HF_HIP(hipStreamSynchronize(ctx->stream));
+        HF_HIP(hipFree(ctx->d_scan_aux));
+        ctx->d_scan_aux = nullptr;
+        ctx->scan_aux_bytes = 0;
+    }
+    size_t cap = (size_t)1 << 16;  // 8 Mi chunks' worth; doubled until it holds this call
+    while (cap < aux) cap *= 2;
+    HF_HIP(hipMalloc(&ctx->d_scan_aux, cap + hf_slot_dump_bytes()));
+    ctx->scan_aux_bytes = cap;
+    return HF_OK;
+}
+
 // run one table stage: h_io (pinned) -> device -> kernel -> h_io, synchronous
 int run_stage(hf_ctx* ctx, int N, int op, int lmax, unsigned long long thr) {
     ctx->h_io->status = -1;
@@ -249,6 +299,22 @@ int hf_flush(hf_ctx* ctx) {
     HF_HIP(hipStreamSynchronize(ctx->stream));
     ctx->last_hip = 0;
     ctx->timed = 0;
+    return HF_OK;
+}
+
+int hf_ctx_reserve(hf_ctx* ctx, uint64_t max_n, unsigned flags) {
+    if (!ctx || (flags & ~(unsigned)HF_RESERVE_ALL) != 0) return HF_ERR_ARG;
+    if (max_n > (1ull << 40)) return HF_ERR_RANGE;
+    HF_USE_DEVICE(ctx);
+    const uint64_t nchunks = hf_num_chunks(max_n);
+    if (flags & HF_RESERVE_ENCODE) {
+        if (int rc = ensure_desc(ctx, nchunks)) return rc;
+        if (int rc = ensure_spill(ctx)) return rc;
+    }
+    if (flags & HF_RESERVE_CODEBOOKS)
+        if (int rc = ensure_cbscratch(ctx)) return rc;
+    if (flags & HF_RESERVE_PLACED)
+        if (int rc = ensure_scan_aux(ctx, nchunks)) return rc;
     return HF_OK;
 }
 
@@ -573,24 +639,9 @@ static int encode_common(hf_ctx* ctx, const void* d_data, uint64_t n, int layout
     if (n > (1ull << 40)) return HF_ERR_RANGE;
     HF_USE_DEVICE(ctx);
     const uint64_t nchunks = hf_num_chunks(n);
-    if (nchunks > ctx->desc_cap) {
-        // grown geometrically (at least 64 Ki descriptors, 512 KiB), so that a context sees a
-        // handful of allocations over its life, whatever sizes it is asked for
-        if (ctx->d_desc) {
-            HF_HIP(hipStreamSynchronize(ctx->stream));
-            HF_HIP(hipFree(ctx->d_desc));
-            ctx->d_desc = nullptr;
-        }
-        size_t cap = ctx->desc_cap ? ctx->desc_cap * 2 : (size_t)65536;
-        ctx->desc_cap = 0;
-        while (cap < nchunks + 2) cap *= 2;
-        // (two words in front of the descriptors hold the tile ticket, so that one memset clears
-        // everything an encode launch starts from)
-        HF_HIP(hipMalloc(&ctx->d_desc, (cap + 2) * sizeof(unsigned long long)));
-        ctx->desc_cap = cap;
-    }
-    if (nchunks && !ctx->d_spill)
-        HF_HIP(hipMalloc(&ctx->d_spill, hf_encode_spill_bytes(ctx->num_cu)));
+    if (int rc = ensure_desc(ctx, nchunks)) return rc;
+    if (nchunks)
+        if (int rc = ensure_spill(ctx)) return rc;
     // (cleared by a kernel of the library's own, not by hipMemsetAsync: under stream capture a
     // memset becomes a graph node of its own kind, and ROCm 7.2 replayed these small ones with a
     // stale fill pattern from the second replay on, which left the ticket full of garbage)
@@ -659,8 +710,8 @@ int hf_system_codebook_chunks_dev(hf_ctx* ctx, const uint32_t* d_freq_chunks, ui
     if (!aligned16(d_freq_chunks) || !aligned16(d_chunk_codebooks)) return HF_ERR_ALIGN;
     if (nchunks > 0x7FFFFFFFull) return HF_ERR_RANGE;
     HF_USE_DEVICE(ctx);
-    if (nchunks && !ctx->d_cbscratch)
-        HF_HIP(hipMalloc(&ctx->d_cbscratch, hf_chunk_cb_scratch_bytes()));
+    if (nchunks)
+        if (int rc = ensure_cbscratch(ctx)) return rc;
     tic(ctx);
     hf_launch_system_chunks(d_freq_chunks, nchunks, mode, min_freq_threshold,
                             reinterpret_cast<hf_chunk_cb*>(d_chunk_codebooks), ctx->d_cbscratch,
@@ -786,20 +837,7 @@ static int encode_slotted_common(hf_ctx* ctx, const void* d_data, uint64_t n, in
     if (n > (1ull << 40)) return HF_ERR_RANGE;
     HF_USE_DEVICE(ctx);
     const uint64_t nchunks = hf_num_chunks(n);
-    const size_t aux = hf_scan_aux_bytes(nchunks + 1);
-    if (aux > ctx->scan_aux_bytes) {
-        if (ctx->d_scan_aux) {
-            HF_HIP(hipStreamSynchronize(ctx->stream));
-            HF_HIP(hipFree(ctx->d_scan_aux));
-            ctx->d_scan_aux = nullptr;
-            ctx->scan_aux_bytes = 0;
-        }
-        size_t cap = (size_t)1 << 16;  // 8 Mi chunks' worth; doubled until it holds this call
-        while (cap < aux) cap *= 2;
-        // (behind the scan's totals: the dump area for words of a chunk that outgrows its slot)
-        HF_HIP(hipMalloc(&ctx->d_scan_aux, cap + hf_slot_dump_bytes()));
-        ctx->scan_aux_bytes = cap;
-    }
+    if (int rc = ensure_scan_aux(ctx, nchunks)) return rc;
     uint32_t* const dump = reinterpret_cast<uint32_t*>(
         reinterpret_cast<unsigned char*>(ctx->d_scan_aux) + ctx->scan_aux_bytes);
     if (nchunks == 0) {
@@ -892,6 +930,129 @@ int hf_chunk_codebook_download(hf_ctx* ctx, const void* d_chunk_codebooks, uint6
     }
     if (mode) *mode = (int)h->mode;
     if (entropy_q16) *entropy_q16 = h->entropy_q16;
+    return HF_OK;
+}
+
+/* ---- paged stream (format version 2) ---------------------------------------------------------------- */
+uint64_t hf_pages_bound_words(uint64_t n) { return hf_num_chunks(n) * (uint64_t)HF_PAGE_MAX_WORDS; }
+
+int hf_encode_pages(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
+                    const void* d_chunk_codebooks, const uint32_t* d_freq_chunks, uint8_t* d_side,
+                    uint32_t* d_payload, uint64_t payload_cap_words, uint32_t* d_page_off,
+                    uint64_t* h_total_words) {
+    if (!ctx || !d_page_off || !layout_ok(layout)) return HF_ERR_ARG;
+    if (n && (!d_data || !d_payload || !d_chunk_codebooks || !d_freq_chunks)) return HF_ERR_ARG;
+    const int lay = norm_layout(layout);
+    if (lay == HF_LAYOUT_BF16_EXP && n && !d_side) return HF_ERR_ARG;
+    if (!aligned16(d_data) || !aligned16(d_side) || !aligned16(d_payload) ||
+        !aligned16(d_page_off) || !aligned16(d_chunk_codebooks) || !aligned16(d_freq_chunks))
+        return HF_ERR_ALIGN;
+    if (n > (1ull << 40)) return HF_ERR_RANGE;
+    HF_USE_DEVICE(ctx);
+    const uint64_t nchunks = hf_num_chunks(n);
+    if (int rc = ensure_scan_aux(ctx, nchunks)) return rc;
+    if (nchunks == 0) {
+        zero_words(d_page_off, 1, ctx->stream);
+    } else {
+        tic(ctx);
+        hf_launch_encode_pages(d_data, n, lay, reinterpret_cast<const hf_chunk_cb*>(d_chunk_codebooks),
+                               d_freq_chunks, d_side, d_payload, payload_cap_words, d_page_off,
+                               ctx->d_scan_aux, ctx->d_ctl + 1, ctx->stream);
+        const hipError_t launch_err = hipGetLastError();
+        toc(ctx);
+        HF_HIP(launch_err);
+    }
+    if (h_total_words) {
+        // error word and total (the scan leaves the last offset in d_ctl[2] too) in one copy
+        HF_HIP(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl, 64, hipMemcpyDeviceToHost, ctx->stream));
+        HF_HIP(hipStreamSynchronize(ctx->stream));
+        *h_total_words = nchunks ? ctx->h_ctl[2] : 0;
+        return report_kernel_errors(ctx);
+    }
+    return HF_OK;
+}
+
+int hf_decode_pages(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
+                    const uint32_t* d_page_off, const uint8_t* d_side, uint64_t n, int layout,
+                    const uint32_t* d_page_ids, const uint32_t* d_out_slots, uint64_t n_ids,
+                    void* d_out, uint64_t n_slots, int check) {
+    if (!ctx || !layout_ok(layout)) return HF_ERR_ARG;
+    if (d_out_slots && !d_page_ids) return HF_ERR_ARG;
+    const uint64_t n_work = d_page_ids ? n_ids : hf_num_chunks(n);
+    if (n_work && (!d_payload || !d_page_off || !d_out)) return HF_ERR_ARG;
+    const int lay = norm_layout(layout);
+    if (lay == HF_LAYOUT_BF16_EXP && n_work && !d_side) return HF_ERR_ARG;
+    if (!aligned16(d_payload) || !aligned16(d_side) || !aligned16(d_out) || !aligned16(d_page_off) ||
+        !aligned16(d_page_ids) || !aligned16(d_out_slots))
+        return HF_ERR_ALIGN;
+    if (n > (1ull << 40) || n_work > 0x7FFFFFFFull || n_slots > 0xFFFFFFFFull) return HF_ERR_RANGE;
+    HF_USE_DEVICE(ctx);
+    if (n_work) {
+        tic(ctx);
+        hf_launch_decode_pages(d_payload, payload_words, d_page_off, d_side, n, lay, d_page_ids,
+                               d_out_slots, n_slots, n_ids, d_out, ctx->d_ctl + 1, ctx->stream);
+        const hipError_t launch_err = hipGetLastError();
+        toc(ctx);
+        HF_HIP(launch_err);
+    }
+    if (check) {
+        HF_HIP(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl, 64, hipMemcpyDeviceToHost, ctx->stream));
+        HF_HIP(hipStreamSynchronize(ctx->stream));
+        return report_kernel_errors(ctx);
+    }
+    return HF_OK;
+}
+
+// The record of a stored page, read back and expanded on the host: ranks the record lists, then
+// the symbols it does not list in ascending order; lengths from the counts per length; canonical
+// codes in rank order.
+int hf_page_codebook_download(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
+                              const uint32_t* d_page_off, uint64_t page, uint16_t* h_code,
+                              uint8_t* h_len, int* mode, uint32_t* entropy_q16) {
+    if (!ctx || !d_payload || !d_page_off) return HF_ERR_ARG;
+    HF_USE_DEVICE(ctx);
+    uint32_t* w = reinterpret_cast<uint32_t*>(ctx->h_io);
+    HF_HIP(hipMemcpyAsync(w, d_page_off + page, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HF_HIP(hipStreamSynchronize(ctx->stream));
+    const uint64_t off0 = w[0], off1 = w[1];
+    if (off1 < off0 || off1 > payload_words || off1 - off0 < HF_PAGE_HDR_WORDS + HF_PAGE_GAP_WORDS)
+        return HF_ERR_CORRUPT;
+    const uint64_t words = off1 - off0;
+    const uint64_t take = words < HF_PAGE_HDR_WORDS + 64u ? words : HF_PAGE_HDR_WORDS + 64u;
+    HF_HIP(hipMemcpyAsync(w, d_payload + off0, 4 * take, hipMemcpyDeviceToHost, ctx->stream));
+    HF_HIP(hipStreamSynchronize(ctx->stream));
+    const uint32_t head = w[0] & 0x1FFu, bits = w[0] >> 10;
+    if ((w[0] >> 29) != 0 || head > 255u ||
+        HF_PAGE_HDR_WORDS + (head + 3u) / 4u + HF_PAGE_GAP_WORDS + ((uint64_t)bits + 31u) / 32u != words)
+        return HF_ERR_CORRUPT;
+    uint8_t r2s[256];
+    bool seen[256] = {false};
+    const uint8_t* listed = reinterpret_cast<const uint8_t*>(w + HF_PAGE_HDR_WORDS);
+    uint32_t p = 0;
+    for (; p < head; ++p) {
+        if (seen[listed[p]]) return HF_ERR_CORRUPT;
+        seen[listed[p]] = true;
+        r2s[p] = listed[p];
+    }
+    for (int s = 0; s < 256; ++s)
+        if (!seen[s]) r2s[p++] = (uint8_t)s;
+    uint32_t total = 0, kraft = 0, next = 0;
+    uint32_t nlen[17] = {0};
+    for (uint32_t d = 1; d <= 16; ++d) {
+        nlen[d] = (w[2 + (d - 1) / 2] >> (16u * ((d - 1) & 1u))) & 0xFFFFu;
+        total += nlen[d];
+        kraft += nlen[d] << (16 - d);
+    }
+    if (total != 256u || kraft > 65536u) return HF_ERR_CORRUPT;
+    p = 0;
+    for (uint32_t d = 1; d <= 16; ++d)
+        for (uint32_t k = 0; k < nlen[d]; ++k, ++p) {
+            if (h_code) h_code[r2s[p]] = (uint16_t)(next >> (16 - d));
+            if (h_len) h_len[r2s[p]] = (uint8_t)d;
+            next += 1u << (16 - d);
+        }
+    if (mode) *mode = (int)((w[0] >> 9) & 1u);
+    if (entropy_q16) *entropy_q16 = w[1];
     return HF_OK;
 }
 

@@ -154,6 +154,21 @@ void hf_launch_cb_to_wire(const hf_chunk_cb* cbs, uint64_t nchunks, hf_wire_chun
                           hipStream_t s);
 void hf_launch_wire_to_cb(const hf_wire_chunk_cb* in, uint64_t nchunks, hf_chunk_cb* cbs,
                           uint32_t* d_err, hipStream_t s);
+// Paged stream (format version 2; layout: include/huffhip.h).
+// (HF_PAGE_HDR_WORDS: head | mode | bits, entropy, 16 length counts; HF_PAGE_GAP_WORDS: 128 region
+// lengths of 12 bits)
+#define HF_PAGE_MAX_WORDS (HF_PAGE_HDR_WORDS + 64u + HF_PAGE_GAP_WORDS + HF_CHUNK_SYMS * 16u / 32u)
+void hf_launch_scan_u32(uint32_t* d_a, uint64_t m, unsigned long long* d_aux,
+                        unsigned long long limit, uint32_t* d_err, hipStream_t s);
+void hf_launch_encode_pages(const void* d_data, uint64_t n, int layout, const hf_chunk_cb* cbs,
+                            const uint32_t* d_freq_chunks, uint8_t* d_side, uint32_t* d_payload,
+                            uint64_t cap_words, uint32_t* d_page_off,
+                            unsigned long long* d_scan_aux, uint32_t* d_err, hipStream_t s);
+void hf_launch_decode_pages(const uint32_t* d_payload, uint64_t payload_words,
+                            const uint32_t* d_page_off, const uint8_t* d_side, uint64_t n,
+                            int layout, const uint32_t* d_page_ids, const uint32_t* d_out_slots,
+                            uint64_t n_slots, uint64_t n_ids, void* d_out, uint32_t* d_err,
+                            hipStream_t s);
 uint64_t hf_fields_side_bytes_impl(uint64_t n, int layout);
 void hf_launch_fields_split(const void* d_data, uint64_t n, int layout, uint8_t* d_sym,
                             uint8_t* d_side, hipStream_t s);

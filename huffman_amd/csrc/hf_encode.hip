@@ -796,6 +796,17 @@ size_t hf_scan_aux_bytes(uint64_t m) {
     return (size_t)((m + kScanPerGroup - 1) / kScanPerGroup + 1) * sizeof(u64);
 }
 
+// In-place exclusive prefix sum of m 32-bit values on the stream (d_aux: hf_scan_aux_bytes(m)); the
+// last value -- the total -- is left in 64 bits at d_aux[number of groups] and in d_err[1], and a
+// total above `limit` sets the overflow bit.
+void hf_launch_scan_u32(uint32_t* d_a, uint64_t m, unsigned long long* d_aux,
+                        unsigned long long limit, uint32_t* d_err, hipStream_t s) {
+    const unsigned ngroups = (unsigned)((m + kScanPerGroup - 1) / kScanPerGroup);
+    hipLaunchKernelGGL(hf_k_scan_local, dim3(ngroups), dim3(256), 0, s, d_a, m, d_aux);
+    hipLaunchKernelGGL(hf_k_scan_groups, dim3(1), dim3(256), 0, s, d_aux, ngroups);
+    hipLaunchKernelGGL(hf_k_scan_add, dim3(ngroups), dim3(256), 0, s, d_a, m, d_aux, limit, d_err);
+}
+
 // slot sizes -> slot offsets (in d_slot_off, nchunks + 1 values) -> chunks encoded in their slots.
 // d_enc / enc_stride: see hf_k_slot_sizes.
 void hf_launch_encode_chunks_slotted(const void* d_data, uint64_t n, int layout,
@@ -811,11 +822,8 @@ void hf_launch_encode_chunks_slotted(const void* d_data, uint64_t n, int layout,
     const unsigned ngroups = (unsigned)((m + kScanPerGroup - 1) / kScanPerGroup);
     hipLaunchKernelGGL(hf_k_slot_sizes, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, s, d_freq_chunks,
                        d_enc, enc_stride, (uint32_t)nchunks, d_slot_off);
-    hipLaunchKernelGGL(hf_k_scan_local, dim3(ngroups), dim3(256), 0, s, d_slot_off, m, d_scan_aux);
-    hipLaunchKernelGGL(hf_k_scan_groups, dim3(1), dim3(256), 0, s, d_scan_aux, ngroups);
     const u64 limit = cap_words < 0xFFFFFFFFull ? cap_words : 0xFFFFFFFFull;
-    hipLaunchKernelGGL(hf_k_scan_add, dim3(ngroups), dim3(256), 0, s, d_slot_off, m, d_scan_aux, limit,
-                       d_err);
+    hf_launch_scan_u32(d_slot_off, m, d_scan_aux, limit, d_err, s);
     const u64* d_total = d_scan_aux + ngroups;
     uint64_t grid = (nchunks + 3) / 4;
     // (measured flat from 4 to 8 workgroups per CU, 7 a hair ahead; 65 registers allow 7

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define HF_ABI_VERSION 2
+#define HF_ABI_VERSION 3
 
 /* error codes */
 #define HF_OK 0
@@ -103,6 +103,20 @@ int hf_flush(hf_ctx* ctx);
 int hf_sync(hf_ctx* ctx);
 const char* hf_error_string(int code);
 int hf_last_hip_error(hf_ctx* ctx);
+/* The context's device workspaces are sized on demand: the tile descriptors and the ~100 MB spill
+ * area of hf_encode / hf_encode_chunks (HF_RESERVE_ENCODE), the 68 MB batch scratch of
+ * hf_system_codebook_chunks_dev (HF_RESERVE_CODEBOOKS), the offset-scan workspace of the slotted
+ * and paged encoders (HF_RESERVE_PLACED).  A call that needs one that is missing or too small
+ * synchronises the stream, frees and allocates -- which a stream under capture, or a loop that
+ * must not allocate, cannot have.  hf_ctx_reserve makes the named workspaces now, sized for streams
+ * of up to max_n elements; afterwards every enqueue-only call on the context with n <= max_n
+ * allocates, frees and synchronises nothing, whatever was called before.  No counterpart in the
+ * reference (its modules own their registers). */
+#define HF_RESERVE_ENCODE 1u
+#define HF_RESERVE_CODEBOOKS 2u
+#define HF_RESERVE_PLACED 4u
+#define HF_RESERVE_ALL 7u
+int hf_ctx_reserve(hf_ctx* ctx, uint64_t max_n, unsigned flags);
 
 /* ---- SymbolStat (symbol_stat.scala:6-58) -------------------------------------------------- */
 /* start + stream of n beats + done: histogram of one block.  freq[s mod N] counts; the
@@ -337,6 +351,61 @@ int hf_decode_chunks_slotted(hf_ctx* ctx, const uint32_t* d_payload, uint64_t pa
                              const void* d_chunk_codebooks, const uint32_t* d_chunk_ids,
                              const uint32_t* d_out_slots, uint64_t n_ids, void* d_out,
                              uint64_t n_slots, int check);
+/* ---- paged stream (format version 2): per-block codebooks, every page self-contained ----------
+ * The reference has no stored form and no decoder (top_encoder.scala:17-21 ends at the {code,
+ * length, mode} beat; decoder/top_decoder.scala:6-10 is an empty bundle; its figure
+ * reports/figs/decoder.svg shows a scheduler feeding parallel sub-decoders).  This is the stored
+ * form for per-block streams that are written once and read page by page (KV-cache pages): a page
+ * is decoded by a workgroup whose four wavefronts are four sub-decoders, its tables built once by
+ * all of them; a page's size follows from its histogram and codebook alone, so every page's place
+ * is known before the encoder starts (no look-back, no slack); and a page carries its own codebook
+ * record, so a reader fetches one contiguous piece per page.
+ *
+ * A page of HF_CHUNK_SYMS symbols has 256 strings of 64 symbols: string (q, l) = the symbols lane l
+ * owns in rounds 8q .. 8q+7 (symbol index ((r * 64 + l) * 8 + j), round r, j = 0..7), their codes
+ * MSB first, symbols past the end of a last, partial page left out.  Strings lie bit-contiguous in
+ * 128 regions: region r = qf * 64 + l (qf = 0, 1) holds string (qf, l) read forward from the
+ * region's first bit and string (qf + 2, l) read backward from its last bit.  Stream bit i of the
+ * strings area is bit 31 - i % 32 of word i / 32.  Page layout in 32-bit words:
+ *     0       head | mode << 9 | B << 10    B = bits of all codes of the page
+ *     1       entropy_q16
+ *     2..9    u16[16]  number of ranks with code length 1 .. 16 (lengths never decrease with the
+ *             rank, codes are canonical in rank order)
+ *     10..    the first `head` symbols in rank order (count desc, symbol asc), a byte each, zero
+ *             padded to a word; head is the smallest number such that the remaining ranks are
+ *             the remaining symbols in ascending order
+ *     then    HF_PAGE_GAP_WORDS words: the region lengths R_0 .. R_127, 12 bits each, field r at
+ *             bits [12 r, 12 r + 12) of the table (bit b of the table = bit b % 32 of word b / 32)
+ *     then    ceil(B / 32) words of strings
+ * d_page_off[c] = first word of page c, d_page_off[nchunks] = the stream's words.
+ *
+ * hf_encode_pages: d_chunk_codebooks and d_freq_chunks as for hf_encode_chunks_slotted (the
+ * records of hf_system_codebook_chunks_dev and the histograms they were built from; a histogram
+ * that is not its page's gives HF_ERR_CORRUPT and that page is not written).  payload_cap_words >=
+ * hf_pages_bound_words(n) always fits; a buffer the pages do not fit gives HF_ERR_OVERFLOW and
+ * nothing is written.  h_total_words as for hf_encode.
+ * hf_decode_pages: all pages to their own places (d_page_ids NULL), the n_ids listed pages to
+ * consecutive pages of d_out (d_out_slots NULL), or to the named pages of a pool of n_slots pages
+ * -- as hf_decode_chunks / hf_decode_chunks_to; listed pages must be full pages.  A damaged page
+ * (sizes that do not match, a record that is not a canonical order, region lengths that do not add
+ * up, strings that do not meet) is reported as HF_ERR_CORRUPT with check != 0; reads and writes
+ * stay inside the page and its output whatever it holds. */
+#define HF_PAGE_HDR_WORDS 10u
+#define HF_PAGE_GAP_WORDS 48u
+uint64_t hf_pages_bound_words(uint64_t n);
+int hf_encode_pages(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
+                    const void* d_chunk_codebooks, const uint32_t* d_freq_chunks, uint8_t* d_side,
+                    uint32_t* d_payload, uint64_t payload_cap_words, uint32_t* d_page_off,
+                    uint64_t* h_total_words);
+int hf_decode_pages(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
+                    const uint32_t* d_page_off, const uint8_t* d_side, uint64_t n, int layout,
+                    const uint32_t* d_page_ids, const uint32_t* d_out_slots, uint64_t n_ids,
+                    void* d_out, uint64_t n_slots, int check);
+/* bulk read of a stored page's record: code/length by symbol, mode, entropy (synchronises) */
+int hf_page_codebook_download(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
+                              const uint32_t* d_page_off, uint64_t page, uint16_t* h_code,
+                              uint8_t* h_len, int* mode, uint32_t* entropy_q16);
+
 /* bulk read of one record: code/length by symbol, mode, entropy (synchronises) */
 int hf_chunk_codebook_download(hf_ctx* ctx, const void* d_chunk_codebooks, uint64_t chunk,
                                uint16_t* h_code, uint8_t* h_len, int* mode, uint32_t* entropy_q16);

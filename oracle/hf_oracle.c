@@ -840,3 +840,264 @@ int orc_rp_decode_blocks(const uint32_t* payload, const uint32_t* chunk_off, siz
     }
     return 0;
 }
+
+/* ---- paged stream (format version 2, per-block codebooks) ----------------------------------
+ * The reference has neither a packed stream nor a decoder (top_encoder.scala:17-21 ends at the
+ * {code, length, mode} beat; decoder/top_decoder.scala:6-10 is an empty bundle whose figure,
+ * reports/figs/decoder.svg, shows a scheduler feeding parallel sub-decoders).  This is the second
+ * stored form of a per-block stream: every page carries its own codebook record and can be found,
+ * sized and decoded on its own, by four sub-decoders at once.  PARITY UNPINNED, as orc_rp_encode.
+ *
+ * A page is ORC_CHUNK_SYMS symbols with one codebook (orc_rp_system_codebook).  Its 256 "strings"
+ * are the codes of 64 symbols each: string (q, l), q = 0..3, l = 0..63, holds the symbols of
+ * rounds 8q .. 8q+7 of lane l (symbol index ((r * 64 + l) * 8 + j), r the round, j = 0..7; the
+ * same ownership as orc_rp_encode), codes MSB first, symbols past the page's end left out.
+ * Strings are stored bit-contiguous, without padding, in 128 regions: region r = qf * 64 + l
+ * (qf = 0, 1) holds string (qf, l) read forward from the region's first bit and string (qf + 2, l)
+ * read BACKWARD from its last bit, so one length per region -- R_r = the bits of both strings --
+ * places 256 independent decoders.  Stream bit i of the strings area is bit 31 - (i mod 32) of its
+ * word i / 32.
+ *
+ * Page layout, 32-bit little-endian words:
+ *   0       head | mode << 9 | B << 10     head: see orc_rp_page_head; mode: 0 bypass / 1 Huffman in
+ *                                          force; B: bits of all codes of the page
+ *   1       entropy_q16
+ *   2..9    u16[16]: number of ranks with code length 1 .. 16 (lengths never decrease with the
+ *           rank, codes are canonical in rank order)
+ *   10..    the first `head` symbols in rank order, one byte each, zero padded to a word; the
+ *           other ranks are the remaining symbols in ascending order
+ *   then    48 words: R_0 .. R_127, 12 bits each, field r at bits [12 r, 12 r + 12) of the table
+ *           (bit b of the table = bit b mod 32 of its word b / 32)
+ *   then    ceil(B / 32) words of strings
+ * page_off[c] = first word of page c, page_off[nchunks] = total.  The size of a page follows from
+ * its histogram and codebook alone (B = sum count x length), so every page's place is known before
+ * any page is encoded. */
+#define PAGE_HDR_WORDS 10u
+#define PAGE_GAP_WORDS 48u
+#define PAGE_SUBS 4u
+#define PAGE_SUB_ROUNDS (ORC_ROUNDS / PAGE_SUBS)
+
+uint32_t orc_rp_page_head(const uint8_t* rank2sym) {
+    uint32_t p = 255;
+    while (p > 0 && rank2sym[p - 1] < rank2sym[p]) --p;
+    return p;
+}
+
+uint64_t orc_rp_page_words(uint32_t head, uint64_t bits) {
+    return PAGE_HDR_WORDS + (head + 3u) / 4u + PAGE_GAP_WORDS + (bits + 31u) / 32u;
+}
+
+uint64_t orc_rp_pages_bound_words(size_t n) {
+    return (uint64_t)orc_num_chunks(n) * orc_rp_page_words(255, (uint64_t)ORC_CHUNK_SYMS * 16u);
+}
+
+static void set_stream_bit(uint32_t* w, uint64_t i) { w[i >> 5] |= 1u << (31u - (unsigned)(i & 31u)); }
+static unsigned get_stream_bit(const uint32_t* w, uint64_t i) {
+    return (w[i >> 5] >> (31u - (unsigned)(i & 31u))) & 1u;
+}
+
+/* bits of string (q, l) of a page of m symbols, and (bits != NULL) the bits themselves, one per byte */
+static unsigned page_string(const uint8_t* sym, size_t m, const uint16_t* code, const uint8_t* len,
+                            unsigned q, unsigned l, uint8_t* bits) {
+    unsigned t = 0;
+    for (unsigned rr = 0; rr < PAGE_SUB_ROUNDS; ++rr)
+        for (unsigned j = 0; j < ORC_GROUP; ++j) {
+            const size_t i = (((size_t)(q * PAGE_SUB_ROUNDS + rr)) * ORC_LANES + l) * ORC_GROUP + j;
+            if (i >= m) continue;
+            const unsigned L = len[sym[i]];
+            for (unsigned b = 0; b < L; ++b, ++t)
+                if (bits) bits[t] = (uint8_t)((code[sym[i]] >> (L - 1 - b)) & 1u);
+        }
+    return t;
+}
+
+/* One page from its symbols and its codebook (code / len by symbol; rank2sym / len_by_rank in
+ * rank order).  Returns the page's words; out may be NULL to size only. */
+uint64_t orc_rp_encode_page(const uint8_t* sym, size_t m, const uint16_t* code, const uint8_t* len,
+                            const uint8_t* rank2sym, const uint8_t* len_by_rank, uint32_t mode,
+                            uint32_t entropy_q16, uint32_t* out) {
+    uint64_t B = 0;
+    for (size_t i = 0; i < m; ++i) B += len[sym[i]];
+    const uint32_t head = orc_rp_page_head(rank2sym);
+    const uint64_t words = orc_rp_page_words(head, B);
+    if (!out) return words;
+    memset(out, 0, (size_t)words * 4u);
+    out[0] = head | ((mode & 1u) << 9) | ((uint32_t)B << 10);
+    out[1] = entropy_q16;
+    for (int p = 0; p < 256; ++p) {
+        const unsigned L = len_by_rank[p];
+        if (L >= 1 && L <= 16) out[2 + (L - 1) / 2] += 1u << (16u * ((L - 1) & 1u));
+    }
+    for (uint32_t p = 0; p < head; ++p) out[PAGE_HDR_WORDS + p / 4] |= (uint32_t)rank2sym[p] << (8u * (p & 3u));
+    uint32_t* gap = out + PAGE_HDR_WORDS + (head + 3u) / 4u;
+    uint32_t* str = gap + PAGE_GAP_WORDS;
+    uint8_t* bits = (uint8_t*)malloc(64u * 16u);
+    uint64_t at = 0;
+    for (unsigned r = 0; r < 128; ++r) {
+        const unsigned qf = r >> 6, l = r & 63u;
+        const unsigned tf = page_string(sym, m, code, len, qf, l, bits);
+        for (unsigned k = 0; k < tf; ++k)
+            if (bits[k]) set_stream_bit(str, at + k);
+        const unsigned tb = page_string(sym, m, code, len, qf + 2, l, bits);
+        const unsigned R = tf + tb;
+        for (unsigned k = 0; k < tb; ++k)
+            if (bits[k]) set_stream_bit(str, at + R - 1 - k);
+        for (unsigned b = 0; b < 12; ++b)
+            if ((R >> b) & 1u) gap[(12u * r + b) >> 5] |= 1u << ((12u * r + b) & 31u);
+        at += R;
+    }
+    free(bits);
+    return words;
+}
+
+/* Per-block codebooks and pages for a whole stream.  mode_req: 0 bypass, 1 Huffman forced, 2 the
+ * entropy decision (orc_aw_adaptive_mode of orc_rp_entropy_q16_u64), 3 best (orc_rp_best_mode).
+ * code / len (optional, nchunks x 256 by raw symbol) receive the tables in force.  Returns the
+ * total words (payload may be NULL to size only). */
+uint64_t orc_rp_encode_pages(const uint8_t* sym, size_t n, uint64_t min_freq_threshold, int mode_req,
+                             uint16_t* code_out, uint8_t* len_out, uint32_t* payload,
+                             uint32_t* page_off) {
+    const size_t nchunks = orc_num_chunks(n);
+    uint64_t pos = 0;
+    for (size_t c = 0; c < nchunks; ++c) {
+        const size_t base = c * (size_t)ORC_CHUNK_SYMS;
+        const size_t m = n - base < ORC_CHUNK_SYMS ? n - base : ORC_CHUNK_SYMS;
+        uint64_t freq[256], sorted[256];
+        uint16_t ids[256], code[256];
+        uint8_t len[256], r2s[256], lbr[256];
+        orc_aw_symbol_stat(sym + base, m, 256, 64, freq);
+        const uint32_t ent = orc_rp_entropy_q16_u64(freq, 256);
+        uint32_t mode = mode_req == 2 ? (uint32_t)orc_aw_adaptive_mode(ent) : mode_req == 3 ? 1u : (uint32_t)(mode_req & 1);
+        if (mode == 1) {
+            orc_rp_system_codebook(freq, 256, 64, min_freq_threshold, 16, code, len);
+            if (mode_req == 3 && !orc_rp_best_mode(freq, len, 256)) mode = 0;
+        }
+        if (mode == 1) {
+            orc_aw_symbol_sort(freq, 256, sorted, ids);
+            for (int p = 0; p < 256; ++p) {
+                r2s[p] = (uint8_t)ids[p];
+                lbr[p] = len[ids[p]];
+            }
+        } else { /* bypass table, top_encoder.scala:131-137: code(i) = i, length = symWidth */
+            for (int s = 0; s < 256; ++s) {
+                code[s] = (uint16_t)s;
+                len[s] = 8;
+                r2s[s] = (uint8_t)s;
+                lbr[s] = 8;
+            }
+        }
+        if (code_out) memcpy(code_out + c * 256, code, sizeof code);
+        if (len_out) memcpy(len_out + c * 256, len, sizeof len);
+        if (page_off) page_off[c] = (uint32_t)pos;
+        pos += orc_rp_encode_page(sym + base, m, code, len, r2s, lbr, mode, ent,
+                                  payload ? payload + pos : NULL);
+    }
+    if (page_off) page_off[nchunks] = (uint32_t)pos;
+    return pos;
+}
+
+/* The codebook of a stored page: code / len by raw symbol, mode, entropy.  Returns 0, or -1 when the
+ * record is not a canonical order or the page's size does not match `words`. */
+int orc_rp_page_codebook(const uint32_t* page, uint64_t words, uint16_t* code, uint8_t* len,
+                         uint32_t* mode, uint32_t* entropy_q16) {
+    if (words < PAGE_HDR_WORDS + PAGE_GAP_WORDS) return -1;
+    const uint32_t head = page[0] & 0x1FFu, B = page[0] >> 10;
+    if (head > 255 || (page[0] >> 29) != 0 || orc_rp_page_words(head, B) != words) return -1;
+    uint8_t r2s[256], seen[256] = {0};
+    for (uint32_t p = 0; p < head; ++p) {
+        r2s[p] = (uint8_t)(page[PAGE_HDR_WORDS + p / 4] >> (8u * (p & 3u)));
+        if (seen[r2s[p]]) return -1;
+        seen[r2s[p]] = 1;
+    }
+    uint32_t p = head;
+    for (int s = 0; s < 256; ++s)
+        if (!seen[s]) r2s[p++] = (uint8_t)s;
+    uint32_t nlen[17] = {0}, total = 0;
+    uint64_t kraft = 0;
+    for (unsigned L = 1; L <= 16; ++L) {
+        nlen[L] = (page[2 + (L - 1) / 2] >> (16u * ((L - 1) & 1u))) & 0xFFFFu;
+        total += nlen[L];
+        kraft += (uint64_t)nlen[L] << (16 - L);
+    }
+    if (total != 256 || kraft > 65536) return -1;
+    uint32_t next = 0; /* left-aligned 16-bit code of the next rank */
+    p = 0;
+    for (unsigned L = 1; L <= 16; ++L)
+        for (uint32_t k = 0; k < nlen[L]; ++k, ++p) {
+            code[r2s[p]] = (uint16_t)(next >> (16 - L));
+            len[r2s[p]] = (uint8_t)L;
+            next += 1u << (16 - L);
+        }
+    if (mode) *mode = (page[0] >> 9) & 1u;
+    if (entropy_q16) *entropy_q16 = page[1];
+    return 0;
+}
+
+/* Returns 0, or -1 if a page does not decode (bad record, region lengths that do not add up to B,
+ * no matching code, a region whose two strings do not meet exactly). */
+int orc_rp_decode_pages(const uint32_t* payload, const uint32_t* page_off, size_t n,
+                        uint8_t* sym_out) {
+    const size_t nchunks = orc_num_chunks(n);
+    uint16_t* tab = (uint16_t*)malloc(65536 * sizeof(uint16_t));
+    int rc = 0;
+    for (size_t c = 0; c < nchunks && rc == 0; ++c) {
+        const size_t base = c * (size_t)ORC_CHUNK_SYMS;
+        const size_t m = n - base < ORC_CHUNK_SYMS ? n - base : ORC_CHUNK_SYMS;
+        const uint32_t* page = payload + page_off[c];
+        const uint64_t words = (uint64_t)page_off[c + 1] - page_off[c];
+        uint16_t code[256];
+        uint8_t len[256];
+        if (page_off[c + 1] < page_off[c] || orc_rp_page_codebook(page, words, code, len, NULL, NULL) != 0) {
+            rc = -1;
+            break;
+        }
+        memset(tab, 0, 65536 * sizeof(uint16_t));
+        for (int s = 0; s < 256; ++s) {
+            const unsigned L = len[s];
+            const unsigned first = (unsigned)code[s] << (16 - L);
+            for (unsigned e = 0; e < (1u << (16 - L)); ++e) tab[first + e] = (uint16_t)((L << 8) | s);
+        }
+        const uint32_t head = page[0] & 0x1FFu, B = page[0] >> 10;
+        const uint32_t* gap = page + PAGE_HDR_WORDS + (head + 3u) / 4u;
+        const uint32_t* str = gap + PAGE_GAP_WORDS;
+        uint64_t at = 0;
+        for (unsigned r = 0; r < 128 && rc == 0; ++r) {
+            unsigned R = 0;
+            for (unsigned b = 0; b < 12; ++b) R |= ((gap[(12u * r + b) >> 5] >> ((12u * r + b) & 31u)) & 1u) << b;
+            if (at + R > B) {
+                rc = -1;
+                break;
+            }
+            unsigned used[2] = {0, 0};
+            for (unsigned dir = 0; dir < 2 && rc == 0; ++dir) {
+                const unsigned q = (r >> 6) + 2 * dir, l = r & 63u;
+                unsigned k = 0;
+                for (unsigned rr = 0; rr < PAGE_SUB_ROUNDS && rc == 0; ++rr)
+                    for (unsigned j = 0; j < ORC_GROUP; ++j) {
+                        const size_t i = (((size_t)(q * PAGE_SUB_ROUNDS + rr)) * ORC_LANES + l) * ORC_GROUP + j;
+                        if (i >= m) continue;
+                        unsigned v = 0; /* the next 16 bits of the string, zeros past the region */
+                        for (unsigned b = 0; b < 16; ++b) {
+                            unsigned bit = 0;
+                            if (k + b < R) bit = get_stream_bit(str, dir ? at + R - 1 - (k + b) : at + k + b);
+                            v = (v << 1) | bit;
+                        }
+                        const uint16_t e = tab[v];
+                        const unsigned L = e >> 8;
+                        if (L == 0 || k + L > R) {
+                            rc = -1;
+                            break;
+                        }
+                        sym_out[base + i] = (uint8_t)(e & 0xFF);
+                        k += L;
+                    }
+                used[dir] = k;
+            }
+            if (rc == 0 && used[0] + used[1] != R) rc = -1;
+            at += R;
+        }
+        if (rc == 0 && at != B) rc = -1;
+    }
+    free(tab);
+    return rc;
+}

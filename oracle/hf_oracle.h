@@ -188,6 +188,29 @@ uint64_t orc_rp_slot_blocks(const uint8_t* sym, size_t n, const uint8_t* len, si
 int orc_rp_decode_blocks(const uint32_t* payload, const uint32_t* chunk_off, size_t n,
                          const uint16_t* code, const uint8_t* len, uint8_t* sym_out);
 
+/* Paged stream (format version 2): the second stored form of a per-block stream, in which every
+ * page of ORC_CHUNK_SYMS symbols carries its own codebook record, has a size that follows from its
+ * histogram and codebook alone, and is decoded by four sub-decoders at once (the reference's only
+ * decoder intent, reports/figs/decoder.svg: a scheduler feeding parallel sub-decoders; its module,
+ * decoder/top_decoder.scala:6-10, is empty).  Layout: the comment above orc_rp_page_head in
+ * hf_oracle.c.  PARITY UNPINNED, as the packed stream above. */
+/* ranks the record lists explicitly: the smallest p such that rank2sym[p .. 255] ascends */
+uint32_t orc_rp_page_head(const uint8_t* rank2sym);
+/* words of a page whose record lists `head` ranks and whose codes take `bits` bits */
+uint64_t orc_rp_page_words(uint32_t head, uint64_t bits);
+uint64_t orc_rp_pages_bound_words(size_t n);
+uint64_t orc_rp_encode_page(const uint8_t* sym, size_t m, const uint16_t* code, const uint8_t* len,
+                            const uint8_t* rank2sym, const uint8_t* len_by_rank, uint32_t mode,
+                            uint32_t entropy_q16, uint32_t* out);
+/* mode_req: 0 bypass, 1 Huffman forced, 2 the entropy decision, 3 best (orc_rp_best_mode) */
+uint64_t orc_rp_encode_pages(const uint8_t* sym, size_t n, uint64_t min_freq_threshold, int mode_req,
+                             uint16_t* code_out, uint8_t* len_out, uint32_t* payload,
+                             uint32_t* page_off);
+int orc_rp_page_codebook(const uint32_t* page, uint64_t words, uint16_t* code, uint8_t* len,
+                         uint32_t* mode, uint32_t* entropy_q16);
+int orc_rp_decode_pages(const uint32_t* payload, const uint32_t* page_off, size_t n,
+                        uint8_t* sym_out);
+
 size_t orc_num_chunks(size_t n);
 /* Upper bound on payload words for n symbols under any codebook with lengths <= 16. */
 uint64_t orc_payload_bound_words(size_t n);

@@ -103,6 +103,19 @@ def _declare(l: C.CDLL) -> None:
     l.orc_rp_slot_blocks.restype = C.c_uint64
     l.orc_rp_decode_blocks.argtypes = [_u32p, _u32p, C.c_size_t, _u16p, _u8p, _u8p]
     l.orc_rp_decode_blocks.restype = C.c_int
+    l.orc_rp_page_head.argtypes = [_u8p]
+    l.orc_rp_page_head.restype = C.c_uint32
+    l.orc_rp_page_words.argtypes = [C.c_uint32, C.c_uint64]
+    l.orc_rp_page_words.restype = C.c_uint64
+    l.orc_rp_pages_bound_words.argtypes = [C.c_size_t]
+    l.orc_rp_pages_bound_words.restype = C.c_uint64
+    l.orc_rp_encode_pages.argtypes = [_u8p, C.c_size_t, C.c_uint64, C.c_int, _u16p, _u8p, _u32p,
+                                      _u32p]
+    l.orc_rp_encode_pages.restype = C.c_uint64
+    l.orc_rp_page_codebook.argtypes = [_u32p, C.c_uint64, _u16p, _u8p, _u32p, _u32p]
+    l.orc_rp_page_codebook.restype = C.c_int
+    l.orc_rp_decode_pages.argtypes = [_u32p, _u32p, C.c_size_t, _u8p]
+    l.orc_rp_decode_pages.restype = C.c_int
     l.orc_num_chunks.argtypes = [C.c_size_t]
     l.orc_num_chunks.restype = C.c_size_t
     l.orc_payload_bound_words.argtypes = [C.c_size_t]
@@ -471,4 +484,65 @@ def rp_decode_blocks(payload, chunk_off, n: int, code, lens) -> np.ndarray:
                                     _p(code, _u16p), _p(lens, _u8p), _p(out, _u8p))
     if rc != 0:
         raise ValueError("payload does not decode")
+    return out[:n]
+
+
+# ---- paged stream (format version 2) -----------------------------------------------------------
+PAGE_HDR_WORDS, PAGE_GAP_WORDS = 10, 48
+
+
+def page_head(rank2sym) -> int:
+    r = _arr(rank2sym, np.uint8)
+    assert r.size == 256
+    return int(lib().orc_rp_page_head(_p(r, _u8p)))
+
+
+def page_words(head: int, bits: int) -> int:
+    return int(lib().orc_rp_page_words(head, bits))
+
+
+def pages_bound_words(n: int) -> int:
+    return int(lib().orc_rp_pages_bound_words(n))
+
+
+def rp_encode_pages(sym, thr: int = 0, mode: int = 1):
+    """Per-block codebooks, every page self-contained: (payload u32, page_off u32[nchunks+1],
+    code u16[nchunks, 256], len u8[nchunks, 256]).  mode: 0 bypass, 1 Huffman, 2 entropy decision,
+    3 best."""
+    sym = _arr(sym, np.uint8)
+    nch = num_chunks(sym.size)
+    off = np.zeros(nch + 1, np.uint32)
+    code = np.zeros((max(nch, 1), 256), np.uint16)
+    lens = np.zeros((max(nch, 1), 256), np.uint8)
+    total = int(lib().orc_rp_encode_pages(_p(sym, _u8p), sym.size, thr, mode, _p(code, _u16p),
+                                          _p(lens, _u8p), None, _p(off, _u32p)))
+    payload = np.zeros(max(total, 1), np.uint32)
+    lib().orc_rp_encode_pages(_p(sym, _u8p), sym.size, thr, mode, _p(code, _u16p), _p(lens, _u8p),
+                              _p(payload, _u32p), _p(off, _u32p))
+    return payload[:total], off, code[:nch], lens[:nch]
+
+
+def rp_page_codebook(payload, page_off, page: int):
+    """(code u16[256], len u8[256], mode, entropy_q16) of a stored page, None if it is damaged."""
+    payload = _arr(payload, np.uint32)
+    page_off = _arr(page_off, np.uint32)
+    a, b = int(page_off[page]), int(page_off[page + 1])
+    pg = np.ascontiguousarray(payload[a:b]) if b > a else np.zeros(1, np.uint32)
+    code = np.zeros(256, np.uint16)
+    lens = np.zeros(256, np.uint8)
+    mode, ent = C.c_uint32(0), C.c_uint32(0)
+    rc = lib().orc_rp_page_codebook(_p(pg, _u32p), max(b - a, 0), _p(code, _u16p), _p(lens, _u8p),
+                                    C.byref(mode), C.byref(ent))
+    return None if rc else (code, lens, int(mode.value), int(ent.value))
+
+
+def rp_decode_pages(payload, page_off, n: int) -> np.ndarray:
+    payload = _arr(payload, np.uint32)
+    if payload.size == 0:
+        payload = np.zeros(1, np.uint32)
+    page_off = _arr(page_off, np.uint32)
+    out = np.zeros(max(n, 1), np.uint8)
+    rc = lib().orc_rp_decode_pages(_p(payload, _u32p), _p(page_off, _u32p), n, _p(out, _u8p))
+    if rc != 0:
+        raise ValueError("pages do not decode")
     return out[:n]

@@ -51,7 +51,7 @@ def test_header_constants_match_binding():
 
 
 def test_host_only_entry_points(lib, orc):
-    assert lib.hf_abi_version() == 2
+    assert lib.hf_abi_version() == 3
     assert lib.hf_error_string(0) == b"ok" and b"aligned" in lib.hf_error_string(-2)
     for n in (0, 1, 16384, 16385, 10**9):
         assert lib.hf_num_chunks(n) == orc.num_chunks(n)
@@ -168,13 +168,94 @@ def test_scala_binding_names_every_entry_point():
 def test_scala_binding_constants_match_the_header():
     hdr = open(HEADER).read()
     scala = open(os.path.join(ROOT, "bindings", "scala", "huffman", "hip", "HuffHip.scala")).read()
-    for obj, prefix in (("Layout", "HF_LAYOUT_"), ("Mode", "HF_MODE_")):
+    for obj, prefix in (("Layout", "HF_LAYOUT_"), ("Mode", "HF_MODE_"), ("Reserve", "HF_RESERVE_")):
         body = re.search(rf"object {obj} \{{(.*?)\n\}}", scala, re.S)
         if body is None:
             body = re.search(rf"object {obj} \{{(.*?)\}}", scala, re.S)
         pairs = dict((k, int(v)) for k, v in re.findall(r"val (\w+) = (\d+)", body.group(1)))
         assert pairs, obj
         for name, value in pairs.items():
-            m = re.search(rf"#define\s+{prefix}{name}\s+(\d+)", hdr)
+            m = re.search(rf"#define\s+{prefix}{name}\s+(\d+)u?\b", hdr)
             assert m and int(m.group(1)) == value, (obj, name)
-        assert len(pairs) == len(re.findall(rf"#define\s+{prefix}\w+\s+\d+", hdr)), obj
+        assert len(pairs) == len(re.findall(rf"#define\s+{prefix}\w+\s+\d+u?\b", hdr)), obj
+
+
+# ---- the Scala binding's signatures against the ctypes ones ------------------------------------
+# JNA type of a Scala parameter -> the class of C type it marshals to
+_SCALA_CLASS = {
+    "Pointer": "ptr", "Long": "i64", "Int": "i32", "String": "str",
+    "Array[Long]": "p64", "LongByReference": "p64", "Array[Short]": "p16",
+    "ShortByReference": "p16", "Array[Byte]": "p8", "IntByReference": "p32",
+    "FloatByReference": "pf32", "PointerByReference": "pptr",
+    "ContainerInfo": "struct hf_container_info", "EntropyConfig": "struct hf_entropy_config",
+}
+# raw memory on the Scala side where the C side takes a struct pointer
+_SCALA_RAW_STRUCTS = {("hf_adaptive_threshold", 3): "struct hf_adaptive_config"}
+
+
+def _ctypes_class(t):
+    if t is C.c_void_p:
+        return "ptr"
+    if t is C.c_char_p:
+        return "str"
+    if t is C.c_uint64:
+        return "i64"
+    if t in (C.c_int, C.c_uint32, C.c_uint):
+        return "i32"
+    if hasattr(t, "_type_") and not isinstance(t._type_, str):  # POINTER(x)
+        x = t._type_
+        if x in (C.c_int, C.c_uint32):
+            return "p32"
+        if issubclass(x, C.Structure):
+            return "struct " + x.__name__
+        return {C.c_uint64: "p64", C.c_uint16: "p16", C.c_uint8: "p8", C.c_float: "pf32",
+                C.c_void_p: "pptr"}[x]
+    raise AssertionError(f"no class for {t}")
+
+
+def scala_signature_mismatches(text):
+    """Every `def hf_*` of trait HuffHip against _lib.SIGNATURES: argument count, the class of
+    each argument (pointer / 64-bit / 32-bit / typed host array / struct) and the result."""
+    from huffman_amd import _lib as L
+    trait = re.search(r"trait HuffHip extends Library \{(.*?)\n\}", text, re.S).group(1)
+    trait = re.sub(r"//[^\n]*", "", trait)
+    bad = []
+    seen = set()
+    for name, args, ret in re.findall(r"def (hf_[a-z0-9_]+)\((.*?)\)\s*:\s*(\w+)", trait, re.S):
+        seen.add(name)
+        if name not in L.SIGNATURES:
+            bad.append(f"{name}: not in the C ABI")
+            continue
+        res, argtypes = L.SIGNATURES[name]
+        params = [a.split(":", 1)[1].strip() for a in args.split(",") if a.strip()]
+        if len(params) != len(argtypes):
+            bad.append(f"{name}: {len(params)} parameters, the C ABI has {len(argtypes)}")
+            continue
+        for i, (sc, ct) in enumerate(zip(params, argtypes)):
+            want = _ctypes_class(ct)
+            got = _SCALA_CLASS.get(sc)
+            if got == "ptr" and _SCALA_RAW_STRUCTS.get((name, i)) == want:
+                continue
+            if got != want:
+                bad.append(f"{name}: parameter {i} is {sc} ({got}), the C ABI has {want}")
+        if _SCALA_CLASS.get(ret) != _ctypes_class(res):
+            bad.append(f"{name}: returns {ret}, the C ABI has {_ctypes_class(res)}")
+    for name in sorted(set(L.SIGNATURES) - seen):
+        bad.append(f"{name}: missing from trait HuffHip")
+    return bad
+
+
+def test_scala_binding_signatures_match_the_c_abi():
+    path = os.path.join(ROOT, "bindings", "scala", "huffman", "hip", "HuffHip.scala")
+    text = open(path).read()
+    assert scala_signature_mismatches(text) == []
+    # the check has teeth: two neighbouring parameters of different classes swapped, a parameter
+    # dropped and a 64-bit count declared as Int are all caught
+    swapped = text.replace("def hf_symbol_stat_dev(ctx: Pointer, dData: Pointer, n: Long, layout: Int,",
+                           "def hf_symbol_stat_dev(ctx: Pointer, dData: Pointer, layout: Int, n: Long,")
+    assert swapped != text
+    assert any("hf_symbol_stat_dev" in m for m in scala_signature_mismatches(swapped))
+    dropped = text.replace("def hf_flush(ctx: Pointer): Int", "def hf_flush(): Int")
+    assert any("hf_flush" in m for m in scala_signature_mismatches(dropped))
+    narrowed = text.replace("def hf_num_chunks(n: Long): Long", "def hf_num_chunks(n: Int): Long")
+    assert any("hf_num_chunks" in m for m in scala_signature_mismatches(narrowed))
