@@ -22,6 +22,8 @@
 //
 // HBM traffic per byte symbol: encode 1 B read + L/8 B written (+ 2.3 KB per page of counts and
 // codebook read for the sizes), decode L/8 B read + 1 B written.
+#include <stdlib.h>
+
 #include "hf_common.h"
 #include "hf_dec_tables.h"
 
@@ -164,18 +166,74 @@ struct EncPageLds {
     uint32_t red[8];
 };
 
-// Second pass of one lane: its 64 codes appended to the bit position `pos` of its own direction's
-// bit space (forward: the strings area as stored; backward: the same area mirrored, bit m of it
-// being stored bit 32 Wn - 1 - m).  Whole words go out as they fill; the first and the last one
-// share their word with a neighbouring string, so every word is OR-ed into its (zeroed) place.
-template <bool FULL, bool BACK, bool IN_LDS>
-__device__ __forceinline__ void emit_string(const uint32_t (&sy)[16], const uint32_t q, const int lane,
-                                            const uint32_t nvalid, const uint32_t tab,
+// First pass of one lane: one table lookup per symbol, the codes of each pair of symbols joined
+// into one word (at most 32 bits) and kept in registers with their lengths (four to a register), so
+// that the second pass -- which can only start once every lane's bit count is known -- needs no
+// table.  Returns the bits of the lane's string.
+//
+// (sub-dword operand selection: the length is the entry's upper half, the code its lower half)
+__device__ __forceinline__ uint32_t join_pair(const uint32_t ea, const uint32_t eb) {
+    uint32_t c;
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0\n\t"
+        "v_or_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+        : "=&v"(c)
+        : "v"(eb), "v"(ea));
+    return c;
+}
+template <int BYTE>
+__device__ __forceinline__ void pair_len_into(uint32_t& packed, const uint32_t ea, const uint32_t eb) {
+    if constexpr (BYTE == 0)
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(packed) : "v"(ea), "v"(eb));
+    else if constexpr (BYTE == 1)
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(packed) : "v"(ea), "v"(eb));
+    else if constexpr (BYTE == 2)
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(packed) : "v"(ea), "v"(eb));
+    else
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(packed) : "v"(ea), "v"(eb));
+}
+
+template <bool FULL>
+__device__ __forceinline__ uint32_t join_string(const uint32_t (&sy)[16], const uint32_t q,
+                                                const int lane, const uint32_t nvalid,
+                                                const uint32_t tab, uint32_t (&comb)[32],
+                                                uint32_t (&clp)[8]) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        uint32_t e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = lds_u32(enc_addr(sy[2 * rr], sy[2 * rr + 1], j, tab));
+        if (!FULL) {
+            const uint32_t i0 = ((q * 8u + (uint32_t)rr) * 64u + (uint32_t)lane) * 8u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (i0 + (uint32_t)j >= nvalid) e[j] = 0;
+        }
+        clp[rr] = 0;
+        comb[4 * rr + 0] = join_pair(e[0], e[1]);
+        pair_len_into<0>(clp[rr], e[0], e[1]);
+        comb[4 * rr + 1] = join_pair(e[2], e[3]);
+        pair_len_into<1>(clp[rr], e[2], e[3]);
+        comb[4 * rr + 2] = join_pair(e[4], e[5]);
+        pair_len_into<2>(clp[rr], e[4], e[5]);
+        comb[4 * rr + 3] = join_pair(e[6], e[7]);
+        pair_len_into<3>(clp[rr], e[6], e[7]);
+        t = __builtin_amdgcn_sad_u8(clp[rr], 0u, t);  // + the four lengths
+    }
+    return t;
+}
+
+// Second pass of one lane: its 32 joined pairs appended at bit position `pos` of its own
+// direction's bit space (forward: the strings area as stored; backward: the same area mirrored, bit
+// m of it being stored bit 32 Wn - 1 - m).  Whole words go out as they fill; the first and the last
+// one share their word with a neighbouring string, so every word is OR-ed into its (zeroed) place.
+template <bool BACK, bool IN_LDS>
+__device__ __forceinline__ void emit_string(const uint32_t (&comb)[32], const uint32_t (&clp)[8],
                                             const uint32_t pos, const uint32_t wn,
                                             uint32_t* __restrict__ img_str,
                                             uint32_t* __restrict__ glob_str) {
-    u64 acc = 0;
-    uint32_t ab = pos & 31u;
+    uint32_t hi = 0, lo = 0;  // the bits not yet written, right-aligned in hi:lo
+    uint32_t ab = pos & 31u;  // their number, with the bits in front of the string's start
     int idx = BACK ? (int)wn - 1 - (int)(pos >> 5) : (int)(pos >> 5);
     auto put = [&](const uint32_t w) {
         const uint32_t v = BACK ? __builtin_bitreverse32(w) : w;
@@ -186,28 +244,18 @@ __device__ __forceinline__ void emit_string(const uint32_t (&sy)[16], const uint
         idx += BACK ? -1 : 1;
     };
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-        uint32_t e[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = lds_u32(enc_addr(sy[2 * rr], sy[2 * rr + 1], j, tab));
-#pragma unroll
-        for (int jp = 0; jp < 4; ++jp) {
-            uint32_t ea = e[2 * jp], eb = e[2 * jp + 1];
-            if (!FULL) {
-                const uint32_t i0 = ((q * 8u + (uint32_t)rr) * 64u + (uint32_t)lane) * 8u + 2u * jp;
-                if (i0 >= nvalid) ea = 0;
-                if (i0 + 1 >= nvalid) eb = 0;
-            }
-            const uint32_t la = ea >> 16, lb = eb >> 16, cl = la + lb;
-            acc = (acc << cl) | (u64)(((ea & 0xFFFFu) << lb) | (eb & 0xFFFFu));
-            ab += cl;
-            if (ab >= 32u) {
-                put((uint32_t)(acc >> (ab - 32u)));
-                ab -= 32u;
-            }
+    for (int p = 0; p < 32; ++p) {
+        const uint32_t cl = (clp[p >> 2] >> (8 * (p & 3))) & 0xFFu;  // 0 .. 32
+        const u64 acc = ((((u64)hi << 32) | (u64)lo) << cl) | (u64)comb[p];
+        hi = (uint32_t)(acc >> 32);
+        lo = (uint32_t)acc;
+        ab += cl;
+        if (ab >= 32u) {
+            put(__builtin_amdgcn_alignbit(hi, lo, ab));  // bits ab - 1 .. ab - 32 of hi:lo
+            ab &= 31u;
         }
     }
-    if (ab != 0u) put((uint32_t)(acc << (32u - ab)));
+    if (ab != 0u) put(lo << (32u - ab));
 }
 
 template <int LAYOUT, bool FULL>
@@ -241,17 +289,9 @@ __device__ __forceinline__ void encode_page(EncPageLds& L, const void* chunk_in,
     __syncthreads();
 
     // first pass: the bits of this lane's string; the record's explicit ranks
+    uint32_t comb[32], clp[8];
     {
-        uint32_t t = 0;
-#pragma unroll
-        for (int rr = 0; rr < 8; ++rr)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                uint32_t len = lds_u16(enc_addr(sy[2 * rr], sy[2 * rr + 1], j, tab) + 2u);
-                if (!FULL && ((q * 8u + (uint32_t)rr) * 64u + (uint32_t)lane) * 8u + (uint32_t)j >= nvalid)
-                    len = 0;
-                t += len;
-            }
+        const uint32_t t = join_string<FULL>(sy, q, lane, nvalid, tab, comb, clp);
         L.tlen[tid] = t;
         const bool desc = tid > 0 && L.r2s[tid - 1] >= L.r2s[tid];
         const u64 m = __ballot(desc);
@@ -321,11 +361,11 @@ __device__ __forceinline__ void encode_page(EncPageLds& L, const void* chunk_in,
         const uint32_t r = (q & 1u) * 64u + (uint32_t)lane;
         const uint32_t pos = q < 2 ? L.rstart[r] : wn * 32u - L.rstart[r + 1];
         if (in_lds) {
-            if (q < 2) emit_string<FULL, false, true>(sy, q, lane, nvalid, tab, pos, wn, img_str, glob_str);
-            else emit_string<FULL, true, true>(sy, q, lane, nvalid, tab, pos, wn, img_str, glob_str);
+            if (q < 2) emit_string<false, true>(comb, clp, pos, wn, img_str, glob_str);
+            else emit_string<true, true>(comb, clp, pos, wn, img_str, glob_str);
         } else {
-            if (q < 2) emit_string<FULL, false, false>(sy, q, lane, nvalid, tab, pos, wn, img_str, glob_str);
-            else emit_string<FULL, true, false>(sy, q, lane, nvalid, tab, pos, wn, img_str, glob_str);
+            if (q < 2) emit_string<false, false>(comb, clp, pos, wn, img_str, glob_str);
+            else emit_string<true, false>(comb, clp, pos, wn, img_str, glob_str);
         }
     }
     __syncthreads();
@@ -377,44 +417,82 @@ __global__ __launch_bounds__(256) void hf_k_encode_pages(
 
 // ---- decoder ---------------------------------------------------------------------------------
 
+// inclusive prefix sum over the 64 lanes of a wavefront, data-parallel-primitive moves only (no
+// LDS crossbar round trips): Hillis-Steele inside each row of 16 lanes, then the row totals
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31
+    return v;
+}
+// the same within rows of 16 lanes only
+__device__ __forceinline__ uint32_t row_scan_incl(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    return v;
+}
+__device__ __forceinline__ uint32_t lane_value(const uint32_t v, const uint32_t l) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
+}
+
 template <int BITS>
 struct DecPageLds {
-    uint16_t lut[1 << BITS];  // first: ChunkTablesT::lookup ORs the table's address into the index
+    uint16_t lut[1 << BITS];  // first: the lookup ORs the table's address into the index
     uint32_t img[kImgWords + kImgSlack];
     uint16_t tail[512];
     uint8_t r2s[256];
     uint32_t present[8];
+    uint32_t cls[20];  // [d]: ranks with codes of at most d bits << 17 | their share of the code space
     uint32_t rstart[132];
     uint32_t used[256];
     uint32_t red[8];
 };
 
-// 16 bytes of the payload at word index idx (a multiple of 4); words at or past the buffer's end
-// read as zero (a buffer whose size is not a multiple of 16 bytes ends in a partial piece)
-__device__ __forceinline__ uint4 load_piece(const uint32_t* __restrict__ payload, const u64 payload_words,
-                                            const u64 idx) {
-    if (idx + 4 <= payload_words) {
-        const hf_u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const hf_u32x4*>(payload + idx));
-        return make_uint4(t.x, t.y, t.z, t.w);
+// Tables of one page, shared by its four wavefronts: a first level of BITS bits (entry: symbol
+// << 8 | length, 0 = the code is longer) and, for the longer codes, a direct table over their part
+// of the 16-bit code space when that part is small (rare symbols: the usual case), the bounds of
+// each length's block otherwise.
+template <int BITS, bool PAIRCHECK>
+struct PageTables {
+    static constexpr int kBits = BITS;
+    static constexpr bool kPairCheck = PAIRCHECK;
+    uint32_t lut_addr, tail_addr, cls_addr, r2s_addr;  // LDS byte addresses (wave-uniform)
+    uint32_t tail_n, tail_start;
+
+    __device__ __forceinline__ uint32_t lookup(const uint32_t top) const {
+        return lds_u16(((top >> (32 - kBits)) << 1) | lut_addr);
     }
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (idx < payload_words) v.x = payload[idx];
-    if (idx + 1 < payload_words) v.y = payload[idx + 1];
-    if (idx + 2 < payload_words) v.z = payload[idx + 2];
-    return v;
-}
+    // entry (symbol << 8 | length) of the code at the top of `top`, 0 if none matches
+    __device__ __forceinline__ uint32_t long_code(const uint32_t top) const {
+        const uint32_t v16 = top >> 16;
+        if (tail_n != 0) {  // wave-uniform
+            const uint32_t idx = v16 - tail_start;
+            return idx < tail_n ? lds_u16(tail_addr + idx * 2u) : 0u;
+        }
+        uint32_t e = 0;
+        for (uint32_t d = 16; d > (uint32_t)kBits; --d) {  // the lowest matching block wins
+            const uint32_t lo = lds_u32(cls_addr + (d - 1u) * 4u), hi = lds_u32(cls_addr + d * 4u);
+            if (v16 < (hi & 0x1FFFFu)) {
+                const uint32_t rank = (lo >> 17) + ((v16 - (lo & 0x1FFFFu)) >> (16u - d));
+                e = (lds_u8(r2s_addr + (rank & 255u)) << 8) | d;
+            }
+        }
+        return v16 >= (lds_u32(cls_addr + (uint32_t)kBits * 4u) & 0x1FFFFu) ? e : 0u;
+    }
+};
 
-// refill of a lane that walks its own words: take the next word when fewer than 32 bits are buffered
-template <bool BACK>
-__device__ __forceinline__ void refill_own(u64& win, int& room, uint32_t& wp) {
-    const uint32_t w0 = lds_u32(wp);
-    const uint32_t w = BACK ? __builtin_bitreverse32(w0) : w0;
-    const bool need = room > 0;
-    win |= (u64)(need ? w : 0u) << (room & 63);
-    room -= need ? 32 : 0;
-    wp += need ? (BACK ? (uint32_t)-4 : 4u) : 0u;
-}
-
+// One lane's walk through its own string.  The window is two registers (hi: the next 32 bits, MSB
+// first; lo: what is buffered behind them) and a count of buffered bits; before a pair of symbols a
+// lane holding fewer than 32 bits takes its next word, which was requested a pair earlier, so the
+// word's LDS latency lies beside the pair's two table lookups and not in front of them.  Inside a
+// pair only `hi` moves (32-bit shifts: 32 valid bits cover two codes); the 64-bit shift happens once
+// per pair.  Backward strings walk down through the words and take each word bit-reversed.
+//
 // the 64 symbols of string (q, lane) of a full page whose image is in LDS; returns the bits consumed
 template <int LAYOUT, bool BACK, class TAB>
 __device__ __forceinline__ uint32_t decode_string(const uint32_t img_str_addr, const uint32_t bitpos,
@@ -424,17 +502,23 @@ __device__ __forceinline__ uint32_t decode_string(const uint32_t img_str_addr, c
     // forward: bitpos = the string's first bit; backward: its first bit too, the region's last
     const uint32_t wi = img_str_addr + (bitpos >> 5) * 4u;
     const uint32_t sh = BACK ? 31u - (bitpos & 31u) : (bitpos & 31u);
-    u64 win;
-    uint32_t wp;
-    if (BACK) {
-        win = ((u64)__builtin_bitreverse32(lds_u32(wi)) << 32) | (u64)__builtin_bitreverse32(lds_u32(wi - 4u));
-        wp = wi - 8u;
-    } else {
-        win = ((u64)lds_u32(wi) << 32) | (u64)lds_u32(wi + 4u);
-        wp = wi + 8u;
+    uint32_t hi, lo, wp;
+    {
+        u64 win;
+        if (BACK) {
+            win = ((u64)__builtin_bitreverse32(lds_u32(wi)) << 32) |
+                  (u64)__builtin_bitreverse32(lds_u32(wi - 4u));
+            wp = wi - 8u;
+        } else {
+            win = ((u64)lds_u32(wi) << 32) | (u64)lds_u32(wi + 4u);
+            wp = wi + 8u;
+        }
+        win <<= sh;
+        hi = (uint32_t)(win >> 32);
+        lo = (uint32_t)win;
     }
-    win <<= sh;
-    int room = (int)sh - 32;
+    uint32_t nb = 64u - sh;         // buffered bits
+    uint32_t wnext = lds_u32(wp);  // the next word, requested ahead
     const hf_gmem_u8* const su = hf_uniform_ptr(side_chunk);
     hf_gmem_u8* const ou = hf_uniform_ptr(out_chunk);
     const uint32_t lane8 = (uint32_t)lane * 8u, lane16 = (uint32_t)lane * 16u;
@@ -445,19 +529,56 @@ __device__ __forceinline__ uint32_t decode_string(const uint32_t img_str_addr, c
             sd[rr] = __builtin_nontemporal_load(
                 reinterpret_cast<const hf_gmem_u32x2*>(su + (q * 8u + (uint32_t)rr) * 512u + lane8));
     }
+    auto long_one = [&](const uint32_t top) -> uint32_t {
+        uint32_t e = T.long_code(top);
+        if (e == 0) {  // no code matches: flag it and keep moving
+            atomicOr(err, HF_KERR_CORRUPT);
+            e = 1;
+        }
+        return e;
+    };
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
         const uint32_t r = q * 8u + (uint32_t)rr;
         uint32_t e[8];
 #pragma unroll
         for (int jp = 0; jp < 4; ++jp) {
-            refill_own<BACK>(win, room, wp);
-            if constexpr (TAB::kPairCheck)
-                decode_pair_single(win, room, T, err, e[2 * jp], e[2 * jp + 1]);
-            else {
-                e[2 * jp] = decode_one(win, room, T, err);
-                e[2 * jp + 1] = decode_one(win, room, T, err);
+            if (nb < 32u) {
+                // fewer than 32 bits: they all sit in hi, lo is empty, and the word goes behind them
+                const uint32_t w = BACK ? __builtin_bitreverse32(wnext) : wnext;
+                hi |= w >> nb;
+                lo = __builtin_amdgcn_alignbit(w, 0u, nb);
+                nb |= 32u;
+                wp += BACK ? (uint32_t)-4 : 4u;
             }
+            wnext = lds_u32(wp);
+            // (a first-level entry of 0 is a longer code: a lane that met one has not moved, its
+            // second lookup returns the same entry, and one test can cover both)
+            uint32_t e0 = T.lookup(hi), e1;
+            if constexpr (TAB::kPairCheck) {
+                e1 = T.lookup(hi << (e0 & 31u));
+                if (__builtin_expect(__ballot(e1 == 0u) != 0ull, 0)) {
+                    if (e1 == 0u) {
+                        if (e0 == 0u) {
+                            e0 = long_one(hi);
+                            e1 = T.lookup(hi << (e0 & 31u));
+                        }
+                        if (e1 == 0u) e1 = long_one(hi << (e0 & 31u));
+                    }
+                }
+            } else {
+                if (__builtin_expect(e0 == 0u, 0)) e0 = long_one(hi);
+                const uint32_t t1 = hi << (e0 & 31u);
+                e1 = T.lookup(t1);
+                if (__builtin_expect(e1 == 0u, 0)) e1 = long_one(t1);
+            }
+            e[2 * jp] = e0;
+            e[2 * jp + 1] = e1;
+            const uint32_t cl = (e0 & 0xFFu) + (e1 & 0xFFu);  // 2 .. 32
+            const u64 win = (((u64)hi << 32) | (u64)lo) << cl;
+            hi = (uint32_t)(win >> 32);
+            lo = (uint32_t)win;
+            nb -= cl;
         }
         if (LAYOUT == HF_LAYOUT_BF16_EXP) {
             // two bf16 per dword (see decode_chunk_full in hf_decode.hip)
@@ -484,7 +605,7 @@ __device__ __forceinline__ uint32_t decode_string(const uint32_t img_str_addr, c
     }
     // words taken x 32, less what is still buffered, less the bits skipped in the first word
     const uint32_t taken = BACK ? (wi + 4u - wp) / 4u - 1u : (wp - wi) / 4u;
-    return taken * 32u - (uint32_t)(32 - room) - sh;
+    return taken * 32u - nb - sh;
 }
 
 // The same for pages that are not full or whose strings stayed in global memory: symbol by symbol,
@@ -517,7 +638,16 @@ __device__ __forceinline__ uint32_t decode_string_slow(const bool back, const ui
                 room -= 32;
                 ++taken;
             }
-            const uint32_t s = decode_one(win, room, T, err) >> 8;
+            const uint32_t top = (uint32_t)(win >> 32);
+            uint32_t e = T.lookup(top);
+            if (e == 0u) e = T.long_code(top);
+            if (e == 0u) {
+                atomicOr(err, HF_KERR_CORRUPT);
+                e = 1;
+            }
+            win <<= (e & 63u);
+            room += (int)(e & 0xFFu);
+            const uint32_t s = e >> 8;
             if (LAYOUT == HF_LAYOUT_BF16_EXP) {
                 const uint32_t b = side_chunk[i];
                 reinterpret_cast<uint16_t*>(out_chunk)[i] =
@@ -530,15 +660,14 @@ __device__ __forceinline__ uint32_t decode_string_slow(const bool back, const ui
     return taken * 32u - (uint32_t)(32 - room) - sh;
 }
 
-template <int LAYOUT, int BITS>
+template <int LAYOUT, int BITS, bool PAIRCHECK>
 __global__ __launch_bounds__(256) void hf_k_decode_pages(
-    const uint32_t* __restrict__ payload, const uint64_t payload_words,
+    const uint32_t* __restrict__ payload, const uint32_t payload_words,
     const uint32_t* __restrict__ page_off, const uint8_t* __restrict__ side, const uint64_t n,
     const uint32_t nchunks, const uint32_t* __restrict__ page_ids,
     const uint32_t* __restrict__ out_slots, const uint32_t n_slots, void* __restrict__ out,
     uint32_t* err) {
-    typedef ChunkTablesT<BITS, 0, (BITS >= 12)> Tab;
-    constexpr int kLong = Tab::kLong;
+    typedef PageTables<BITS, PAIRCHECK> Tab;
     __shared__ __attribute__((aligned(2 << BITS))) DecPageLds<BITS> L;
     const int lane = hf_lane();
     const uint32_t tid = threadIdx.x;
@@ -556,24 +685,38 @@ __global__ __launch_bounds__(256) void hf_k_decode_pages(
     const uint64_t first = (uint64_t)c * HF_CHUNK_SYMS;
     const uint64_t left = n - first;
     const uint32_t nvalid = left < HF_CHUNK_SYMS ? (uint32_t)left : HF_CHUNK_SYMS;
-    if (off1 < off0 || (uint64_t)off1 > payload_words || off1 - off0 < kHdr + kGap ||
+    if (off1 < off0 || off1 > payload_words || off1 - off0 < kHdr + kGap ||
         off1 - off0 > HF_PAGE_MAX_WORDS || (page_ids && nvalid != HF_CHUNK_SYMS))
         return bad();
     const uint32_t words = off1 - off0;
     const uint32_t a0 = off0 & 3u;
-    const u64 base = (u64)(off0 - a0);
+    const uint32_t base = off0 - a0;
     const bool in_lds = a0 + words <= (uint32_t)kImgWords;
     // the page (its header part when it is too large for the image) on its way to LDS, 16 bytes
-    // per thread and step, all steps requested before the first is used
+    // per thread and step, all steps requested before the first is used; the buffer's last, partial
+    // piece (a buffer whose size is not a multiple of 16 bytes) is fetched word by word
     constexpr int kSteps = (kImgWords + 1023) / 1024;
     const uint32_t nload = in_lds ? a0 + words : a0 + kHdr + 64u + kGap;
+    const uint32_t whole = payload_words & ~3u;
     uint4 v[kSteps];
 #pragma unroll
     for (int j = 0; j < kSteps; ++j) {
-        const uint32_t g = tid + 256u * (uint32_t)j;
-        v[j] = g * 4u < nload ? load_piece(payload, payload_words, base + g * 4u) : make_uint4(0, 0, 0, 0);
+        const uint32_t at = (tid + 256u * (uint32_t)j) * 4u;
+        v[j] = make_uint4(0, 0, 0, 0);
+        if (at < nload) {
+            if (__builtin_expect(base + at < whole, 1)) {
+                const hf_u32x4 t =
+                    __builtin_nontemporal_load(reinterpret_cast<const hf_u32x4*>(payload + base + at));
+                v[j] = make_uint4(t.x, t.y, t.z, t.w);
+            } else {
+                const uint32_t i = base + at;
+                if (i < payload_words) v[j].x = payload[i];
+                if (i + 1 < payload_words) v[j].y = payload[i + 1];
+                if (i + 2 < payload_words) v[j].z = payload[i + 2];
+            }
+        }
     }
-    // cleared tables: first-level entries no short code covers are escapes, tail entries no code
+    // cleared tables: first-level entries no short code covers say "longer", tail entries no code
     // covers match nothing
 #pragma unroll
     for (int j = 0; j < (2 << BITS) / 16 / 256; ++j)
@@ -584,33 +727,28 @@ __global__ __launch_bounds__(256) void hf_k_decode_pages(
     __syncthreads();
 
     // ---- the record ----
-    const uint32_t hdr = L.img[a0];
+    const uint32_t hdr = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.img[a0]);
     const uint32_t head = hdr & 0x1FFu, B = hdr >> 10;
     if ((hdr >> 29) != 0u || head > 255u || page_words(head, B) != words) return bad();
     const uint32_t hw = (head + 3u) / 4u;
-    // lengths: rank tid has the smallest length L with cum(L) > tid; ranks of one length tile the
-    // left-aligned 16-bit code space from cs16(L) on, 2^(16-L) values each
-    uint32_t my_len = 0, my_start = 0, total = 0, kraft = 0;
-    uint32_t cum_short = 0;            // ranks with codes of at most BITS bits
-    uint32_t lstart[kLong], lend[kLong], loff[kLong];
-#pragma unroll
-    for (uint32_t d = 1; d <= 16; ++d) {
-        const uint32_t cnt = (L.img[a0 + 2 + (d - 1) / 2] >> (16u * ((d - 1) & 1u))) & 0xFFFFu;
-        if (my_len == 0 && tid < total + cnt) {
-            my_len = d;
-            my_start = kraft + ((tid - total) << (16 - d));
-        }
-        if (d > (uint32_t)BITS) {
-            lstart[d - BITS - 1] = kraft;
-            loff[d - BITS - 1] = total;
-            lend[d - BITS - 1] = kraft + (cnt << (16 - d));
-        }
-        total += cnt;
-        kraft += cnt << (16 - d);
-        if (d == (uint32_t)BITS) cum_short = total;
-    }
-    (void)cum_short;
+    // Lengths never decrease with the rank and the codes of one length tile the left-aligned 16-bit
+    // code space one after the other.  Lane d - 1 takes length d: ranks with at most d bits (cum)
+    // and the code space they fill (cs), by two scans over 16 lanes; rank tid then has the smallest
+    // length whose cum exceeds it -- one compare against each of 15 scalars.
+    const uint32_t cnt = lane < 16 ? reinterpret_cast<const uint16_t*>(L.img + a0 + 2)[lane] : 0u;
+    const uint32_t cumv = row_scan_incl(cnt);
+    const uint32_t csv = row_scan_incl(cnt << (15 - (lane & 15)));
+    const uint32_t total = lane_value(cumv, 15), kraft = lane_value(csv, 15);
     if (total != 256u || kraft > 65536u) return bad();
+    uint32_t my_len = 1;
+#pragma unroll
+    for (uint32_t d = 1; d <= 15; ++d) my_len += tid >= lane_value(cumv, d - 1) ? 1u : 0u;
+    if (q == 0 && lane <= 16) {
+        // cls[d] for d = 0 .. 16 (lane d takes the values of lane d - 1)
+        const uint32_t pc = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)((cumv << 17) | csv), 0x111,
+                                                                  0xF, 0xF, true);
+        L.cls[lane] = lane == 16 ? (256u << 17) | kraft : pc;
+    }
     if (tid < head) {
         const uint32_t s = reinterpret_cast<const uint8_t*>(L.img + a0 + kHdr)[tid];
         L.r2s[tid] = (uint8_t)s;
@@ -618,39 +756,32 @@ __global__ __launch_bounds__(256) void hf_k_decode_pages(
                               __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     // region lengths and their prefix sum (wavefronts 0 and 1: one region per thread)
-    uint32_t R = 0;
+    uint32_t R = 0, incl = 0;
     if (q < 2) {
         const uint32_t* gap = L.img + a0 + kHdr + hw;
         const uint32_t bit = 12u * tid;
-        const u64 two = ((u64)gap[(bit >> 5) + 1] << 32) | (u64)gap[bit >> 5];
-        R = (uint32_t)(two >> (bit & 31u)) & 0xFFFu;
-        uint32_t incl = R;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(incl, o);
-            if (lane >= o) incl += t;
-        }
+        R = __builtin_amdgcn_alignbit(gap[(bit >> 5) + 1], gap[bit >> 5], bit & 31u) & 0xFFFu;
+        incl = wave_scan_incl(R);
         if (q == 0 && lane == 63) L.red[0] = incl;
-        L.used[tid] = incl;  // (parked: the inclusive sum within the wavefront)
     }
     __syncthreads();
 
-    uint32_t npresent = 0;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) npresent += (uint32_t)__popc(L.present[w]);
-    if (npresent != head) return bad();  // a symbol listed twice
     {
-        // the ranks behind the listed ones: the symbols not listed, ascending
-        const uint32_t s = tid, w = s >> 5;
-        uint32_t below = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) below += (uint32_t)i < w ? (uint32_t)__popc(L.present[i]) : 0u;
+        // The ranks behind the listed ones: the symbols not listed, ascending.  Symbol s = tid is
+        // not listed <=> its bit of `present` is clear, and then its rank is head + s - (listed
+        // symbols below s).  Lane i < 8 counts word i; a scan gives the counts below each word.
+        const uint32_t pcv = row_scan_incl(lane < 8 ? (uint32_t)__popc(L.present[lane & 7]) : 0u);
+        if (lane_value(pcv, 7) != head) return bad();  // a symbol listed twice
+        const uint32_t w = tid >> 5;                   // 2 q or 2 q + 1
+        const uint32_t before = q == 0 ? 0u : lane_value(pcv, 2u * q - 1u);
+        const uint32_t mid = lane_value(pcv, 2u * q) - before;  // listed symbols in word 2 q
         const uint32_t mine = L.present[w];
-        below += (uint32_t)__popc(mine & ((1u << (s & 31u)) - 1u));
-        if (!((mine >> (s & 31u)) & 1u)) L.r2s[head + s - below] = (uint8_t)s;
+        const uint32_t below = before + (lane >= 32 ? mid : 0u) +
+                               (uint32_t)__popc(mine & ((1u << (tid & 31u)) - 1u));
+        if (!((mine >> (tid & 31u)) & 1u)) L.r2s[head + tid - below] = (uint8_t)tid;
     }
     if (q < 2) {
-        const uint32_t incl = L.used[tid] + (q == 1 ? L.red[0] : 0u);
+        incl += q == 1 ? L.red[0] : 0u;
         L.rstart[tid] = incl - R;
         if (tid == 127) L.rstart[128] = incl;
     }
@@ -665,38 +796,35 @@ __global__ __launch_bounds__(256) void hf_k_decode_pages(
     // ---- tables ----
     Tab T;
     {
+        const uint32_t pc = L.cls[my_len - 1];
+        const uint32_t my_start = (pc & 0x1FFFFu) + ((tid - (pc >> 17)) << (16u - my_len));
         const uint32_t val = ((uint32_t)L.r2s[tid] << 8) | my_len;
         const uint32_t v2 = val | (val << 16);
-        auto fill = [&](uint16_t* base, const uint32_t at, const uint32_t span) {
+        // (a code's span starts at a multiple of its size: the widest aligned store that fits)
+        auto fill = [&](uint16_t* to, const uint32_t at, const uint32_t span) {
             if (span >= 8) {
                 for (uint32_t i = 0; i < span; i += 8)
-                    *reinterpret_cast<uint4*>(base + at + i) = make_uint4(v2, v2, v2, v2);
+                    *reinterpret_cast<uint4*>(to + at + i) = make_uint4(v2, v2, v2, v2);
             } else if (span == 4) {
-                *reinterpret_cast<uint2*>(base + at) = make_uint2(v2, v2);
+                *reinterpret_cast<uint2*>(to + at) = make_uint2(v2, v2);
             } else if (span == 2) {
-                *reinterpret_cast<uint32_t*>(base + at) = v2;
+                *reinterpret_cast<uint32_t*>(to + at) = v2;
             } else {
-                base[at] = (uint16_t)val;
+                to[at] = (uint16_t)val;
             }
         };
-        // the long codes' part of the code space; a direct table when it is small (rare symbols:
-        // the usual case), the blocks' bounds otherwise
-        const uint32_t tail_span = lend[kLong - 1] - lstart[0];
-        const uint32_t tail_n = tail_span <= 512u ? tail_span : 0u;
+        const uint32_t tail_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)(L.cls[BITS] & 0x1FFFFu));
+        const uint32_t tail_span = kraft - tail_start;
+        T.tail_n = tail_span <= 512u ? tail_span : 0u;
+        T.tail_start = tail_start;
         if (my_len <= (uint32_t)BITS)
             fill(L.lut, my_start >> (16 - BITS), 1u << (BITS - my_len));
-        else if (tail_n != 0)
-            fill(L.tail, my_start - lstart[0], 1u << (16 - my_len));
+        else if (T.tail_n != 0)
+            fill(L.tail, my_start - tail_start, 1u << (16u - my_len));
         T.lut_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(L.lut));
-        T.rank2sym = L.r2s;
-        T.tail = L.tail;
-        T.tail_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)tail_n);
-#pragma unroll
-        for (int i = 0; i < kLong; ++i) {
-            T.start[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lstart[i]);
-            T.end[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lend[i]);
-            T.off[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)loff[i]);
-        }
+        T.tail_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(L.tail));
+        T.cls_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(L.cls));
+        T.r2s_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(L.r2s));
     }
     __syncthreads();
     if (L.rstart[128] != B) return bad();  // the regions do not add up to the page's bits
@@ -773,12 +901,24 @@ void hf_launch_decode_pages(const uint32_t* d_payload, uint64_t payload_words,
     const uint64_t nchunks = (n + HF_CHUNK_SYMS - 1) / HF_CHUNK_SYMS;
     const uint64_t n_work = d_page_ids ? n_ids : nchunks;
     if (n_work == 0) return;
-    if (layout == HF_LAYOUT_BF16_EXP)
-        hipLaunchKernelGGL((hf_k_decode_pages<HF_LAYOUT_BF16_EXP, 11>), dim3((unsigned)n_work),
-                           dim3(256), 0, s, d_payload, payload_words, d_page_off, d_side, n,
-                           (uint32_t)nchunks, d_page_ids, d_out_slots, (uint32_t)n_slots, d_out, d_err);
-    else
-        hipLaunchKernelGGL((hf_k_decode_pages<HF_LAYOUT_U8, 11>), dim3((unsigned)n_work), dim3(256), 0,
-                           s, d_payload, payload_words, d_page_off, (const uint8_t*)nullptr, n,
-                           (uint32_t)nchunks, d_page_ids, d_out_slots, (uint32_t)n_slots, d_out, d_err);
+    // (page offsets are 32-bit word indices: nothing behind 2^32 words is ever addressed)
+    const uint32_t pw32 = payload_words > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)payload_words;
+    // (experiment switch: first-level width and where the escape test sits)
+    static const int variant = getenv("HF_PAGES_VARIANT") ? atoi(getenv("HF_PAGES_VARIANT")) : 0;
+#define HF_LAUNCH_DEC(LAY, BITS, PC, SIDE)                                                          \
+    hipLaunchKernelGGL((hf_k_decode_pages<LAY, BITS, PC>), dim3((unsigned)n_work), dim3(256), 0, s,  \
+                       d_payload, pw32, d_page_off, SIDE, n, (uint32_t)nchunks, d_page_ids,          \
+                       d_out_slots, (uint32_t)n_slots, d_out, d_err)
+    if (layout == HF_LAYOUT_BF16_EXP) {
+        HF_LAUNCH_DEC(HF_LAYOUT_BF16_EXP, 11, false, d_side);
+    } else if (variant == 1) {
+        HF_LAUNCH_DEC(HF_LAYOUT_U8, 11, true, (const uint8_t*)nullptr);
+    } else if (variant == 2) {
+        HF_LAUNCH_DEC(HF_LAYOUT_U8, 12, true, (const uint8_t*)nullptr);
+    } else if (variant == 3) {
+        HF_LAUNCH_DEC(HF_LAYOUT_U8, 12, false, (const uint8_t*)nullptr);
+    } else {
+        HF_LAUNCH_DEC(HF_LAYOUT_U8, 11, false, (const uint8_t*)nullptr);
+    }
+#undef HF_LAUNCH_DEC
 }
