@@ -1109,30 +1109,41 @@ namespace {
 
 inline uint64_t up16(uint64_t x) { return (x + 15ull) & ~15ull; }
 
-// section offsets of a version-1 container; false when the request is not representable
-bool plan_container(uint64_t n, int layout, int kind, uint64_t payload_words,
+// section offsets of a container; false when the request is not representable
+bool plan_container(uint64_t n, int layout, int kind, int placement, uint64_t payload_words,
                     hf_container_info* info) {
     if ((!layout_ok(layout) && !front_end_layout(layout)) ||
         (kind != HF_CODEBOOK_STREAM && kind != HF_CODEBOOK_PER_CHUNK))
         return false;
+    if (placement != HF_PLACEMENT_DENSE && placement != HF_PLACEMENT_SLOTTED &&
+        placement != HF_PLACEMENT_PAGED)
+        return false;
+    if (placement == HF_PLACEMENT_PAGED && kind != HF_CODEBOOK_PER_CHUNK) return false;
     if (layout == HF_LAYOUT_BITPLANE8 && n % 8 != 0) return false;
     if (n > (1ull << 40) || payload_words > 0xFFFFFFFFull) return false;
     const uint64_t nchunks = hf_num_chunks(n);
     memset(info, 0, sizeof(*info));
-    info->version = HF_CONTAINER_VERSION;
+    info->version = placement == HF_PLACEMENT_DENSE ? 1u : 2u;
     info->layout = (uint32_t)layout;
     info->codebook_kind = (uint32_t)kind;
+    info->placement = (uint32_t)placement;
     info->chunk_syms = HF_CHUNK_SYMS;
     info->max_code_len = HF_MAX_CODE_LEN;
     info->n = n;
     info->nchunks = nchunks;
     info->payload_words = payload_words;
     uint64_t off = HF_CONTAINER_HEADER_BYTES;
-    info->off_codebook = off;
-    off += kind == HF_CODEBOOK_STREAM ? 768ull : nchunks * HF_CONTAINER_CHUNK_CODEBOOK_BYTES;
-    off = up16(off);
+    if (placement != HF_PLACEMENT_PAGED) {
+        info->off_codebook = off;
+        off += kind == HF_CODEBOOK_STREAM ? 768ull : nchunks * HF_CONTAINER_CHUNK_CODEBOOK_BYTES;
+        off = up16(off);
+    }
     info->off_chunk_off = off;
     off = up16(off + 4ull * (nchunks + 1));
+    if (placement == HF_PLACEMENT_SLOTTED) {
+        info->off_chunk_words = off;
+        off = up16(off + 4ull * nchunks);
+    }
     if (layout == HF_LAYOUT_BF16_EXP || side_bytes(n, layout) != 0) {
         info->off_side = off;
         off = up16(off + side_bytes(n, layout));
@@ -1153,63 +1164,88 @@ uint64_t get64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
 
 int hf_container_plan(uint64_t n, int layout, int codebook_kind, uint64_t payload_words,
                       hf_container_info* info) {
+    return hf_container_plan_placed(n, layout, codebook_kind, HF_PLACEMENT_DENSE, payload_words,
+                                    info);
+}
+
+int hf_container_plan_placed(uint64_t n, int layout, int codebook_kind, int placement,
+                             uint64_t payload_words, hf_container_info* info) {
     if (!info) return HF_ERR_ARG;
-    return plan_container(n, layout, codebook_kind, payload_words, info) ? HF_OK : HF_ERR_ARG;
+    return plan_container(n, layout, codebook_kind, placement, payload_words, info) ? HF_OK
+                                                                                    : HF_ERR_ARG;
 }
 
 int hf_container_pack(hf_ctx* ctx, hf_container_info* info, const void* d_codebook,
                       const uint32_t* d_chunk_off, const uint8_t* d_side,
                       const uint32_t* d_payload, void* d_blob, uint64_t blob_cap_bytes) {
-    if (!ctx || !info || !d_codebook || !d_chunk_off || !d_blob) return HF_ERR_ARG;
+    return hf_container_pack_placed(ctx, info, d_codebook, d_chunk_off, nullptr, d_side, d_payload,
+                                    d_blob, blob_cap_bytes);
+}
+
+int hf_container_pack_placed(hf_ctx* ctx, hf_container_info* info, const void* d_codebook,
+                             const uint32_t* d_chunk_off, const uint32_t* d_chunk_words,
+                             const uint8_t* d_side, const uint32_t* d_payload, void* d_blob,
+                             uint64_t blob_cap_bytes) {
+    if (!ctx || !info || !d_chunk_off || !d_blob) return HF_ERR_ARG;
     hf_container_info pl;
-    if (!plan_container(info->n, (int)info->layout, (int)info->codebook_kind, info->payload_words,
-                        &pl))
+    if (!plan_container(info->n, (int)info->layout, (int)info->codebook_kind, (int)info->placement,
+                        info->payload_words, &pl))
         return HF_ERR_ARG;
+    if (pl.off_codebook && !d_codebook) return HF_ERR_ARG;
     if (pl.payload_words && !d_payload) return HF_ERR_ARG;
     if (pl.off_side && pl.n && !d_side) return HF_ERR_ARG;
+    if (pl.off_chunk_words && pl.nchunks && !d_chunk_words) return HF_ERR_ARG;
     if (!aligned16(d_blob) || !aligned16(d_codebook)) return HF_ERR_ALIGN;
     if (blob_cap_bytes < pl.total_bytes) return HF_ERR_OVERFLOW;
     HF_USE_DEVICE(ctx);
     uint8_t* blob = reinterpret_cast<uint8_t*>(d_blob);
     hipStream_t s = ctx->stream;
     tic(ctx);
-    // codebook section
-    uint64_t end;
-    if (pl.codebook_kind == HF_CODEBOOK_STREAM) {
-        const hf_cb_dev* cb = reinterpret_cast<const hf_cb_dev*>(d_codebook);
-        HF_HIP(hipMemcpyAsync(blob + pl.off_codebook, cb->code, 512, hipMemcpyDeviceToDevice, s));
-        HF_HIP(hipMemcpyAsync(blob + pl.off_codebook + 512, cb->len, 256, hipMemcpyDeviceToDevice, s));
-        HF_HIP(hipMemcpyAsync(ctx->h_ctl, &cb->mode, 8, hipMemcpyDeviceToHost, s));  // mode, entropy
-        end = pl.off_codebook + 768;
-    } else {
-        hf_launch_cb_to_wire(reinterpret_cast<const hf_chunk_cb*>(d_codebook), pl.nchunks,
-                             reinterpret_cast<hf_wire_chunk_cb*>(blob + pl.off_codebook), s);
-        HF_HIP(hipGetLastError());
-        end = pl.off_codebook + pl.nchunks * HF_CONTAINER_CHUNK_CODEBOOK_BYTES;
+    // a section, then zeros up to the next one
+    uint64_t end = HF_CONTAINER_HEADER_BYTES;
+    auto pad_to = [&](uint64_t next) -> hipError_t {
+        return next > end ? hipMemsetAsync(blob + end, 0, next - end, s) : hipSuccess;
+    };
+    if (pl.off_codebook) {
+        if (pl.codebook_kind == HF_CODEBOOK_STREAM) {
+            const hf_cb_dev* cb = reinterpret_cast<const hf_cb_dev*>(d_codebook);
+            HF_HIP(hipMemcpyAsync(blob + pl.off_codebook, cb->code, 512, hipMemcpyDeviceToDevice, s));
+            HF_HIP(hipMemcpyAsync(blob + pl.off_codebook + 512, cb->len, 256, hipMemcpyDeviceToDevice, s));
+            HF_HIP(hipMemcpyAsync(ctx->h_ctl, &cb->mode, 8, hipMemcpyDeviceToHost, s));  // mode, entropy
+            end = pl.off_codebook + 768;
+        } else {
+            hf_launch_cb_to_wire(reinterpret_cast<const hf_chunk_cb*>(d_codebook), pl.nchunks,
+                                 reinterpret_cast<hf_wire_chunk_cb*>(blob + pl.off_codebook), s);
+            HF_HIP(hipGetLastError());
+            end = pl.off_codebook + pl.nchunks * HF_CONTAINER_CHUNK_CODEBOOK_BYTES;
+        }
     }
-    if (pl.off_chunk_off > end) HF_HIP(hipMemsetAsync(blob + end, 0, pl.off_chunk_off - end, s));
-    // chunk offsets
+    HF_HIP(pad_to(pl.off_chunk_off));
     HF_HIP(hipMemcpyAsync(blob + pl.off_chunk_off, d_chunk_off, 4ull * (pl.nchunks + 1),
                           hipMemcpyDeviceToDevice, s));
     end = pl.off_chunk_off + 4ull * (pl.nchunks + 1);
-    const uint64_t after_off = pl.off_side ? pl.off_side : pl.off_payload;
-    if (after_off > end) HF_HIP(hipMemsetAsync(blob + end, 0, after_off - end, s));
-    // side bytes
+    if (pl.off_chunk_words) {
+        HF_HIP(pad_to(pl.off_chunk_words));
+        if (pl.nchunks)
+            HF_HIP(hipMemcpyAsync(blob + pl.off_chunk_words, d_chunk_words, 4ull * pl.nchunks,
+                                  hipMemcpyDeviceToDevice, s));
+        end = pl.off_chunk_words + 4ull * pl.nchunks;
+    }
     if (pl.off_side) {
+        HF_HIP(pad_to(pl.off_side));
         const uint64_t sb = side_bytes(pl.n, (int)pl.layout);
         if (sb) HF_HIP(hipMemcpyAsync(blob + pl.off_side, d_side, sb, hipMemcpyDeviceToDevice, s));
         end = pl.off_side + sb;
-        if (pl.off_payload > end) HF_HIP(hipMemsetAsync(blob + end, 0, pl.off_payload - end, s));
     }
-    // payload
+    HF_HIP(pad_to(pl.off_payload));
     if (pl.payload_words)
         HF_HIP(hipMemcpyAsync(blob + pl.off_payload, d_payload, 4ull * pl.payload_words,
                               hipMemcpyDeviceToDevice, s));
     end = pl.off_payload + 4ull * pl.payload_words;
-    if (pl.total_bytes > end) HF_HIP(hipMemsetAsync(blob + end, 0, pl.total_bytes - end, s));
+    HF_HIP(pad_to(pl.total_bytes));
     toc(ctx);
     HF_HIP(hipStreamSynchronize(s));
-    if (pl.codebook_kind == HF_CODEBOOK_STREAM) {
+    if (pl.off_codebook && pl.codebook_kind == HF_CODEBOOK_STREAM) {
         pl.mode = ctx->h_ctl[0];
         pl.entropy_q16 = ctx->h_ctl[1];
     } else {
@@ -1235,6 +1271,10 @@ int hf_container_pack(hf_ctx* ctx, hf_container_info* info, const void* d_codebo
     put64(h + 80, pl.off_side);
     put64(h + 88, pl.off_payload);
     put64(h + 96, pl.total_bytes);
+    if (pl.version >= 2) {
+        put32(h + 104, pl.placement);
+        put64(h + 112, pl.off_chunk_words);
+    }
     HF_HIP(hipMemcpyAsync(blob, h, HF_CONTAINER_HEADER_BYTES, hipMemcpyHostToDevice, s));
     HF_HIP(hipStreamSynchronize(s));
     *info = pl;
@@ -1251,18 +1291,26 @@ int hf_container_open(hf_ctx* ctx, const void* d_blob, uint64_t blob_bytes,
     HF_HIP(hipMemcpyAsync(h, d_blob, HF_CONTAINER_HEADER_BYTES, hipMemcpyDeviceToHost, ctx->stream));
     HF_HIP(hipStreamSynchronize(ctx->stream));
     if (memcmp(h, "HUFHIP1", 8) != 0) return HF_ERR_CORRUPT;
-    if (get32(h + 8) != HF_CONTAINER_VERSION || get32(h + 12) != HF_CONTAINER_HEADER_BYTES)
+    const uint32_t version = get32(h + 8);
+    if ((version != 1 && version != 2) || get32(h + 12) != HF_CONTAINER_HEADER_BYTES)
         return HF_ERR_CORRUPT;
     if (get32(h + 24) != HF_CHUNK_SYMS || get32(h + 28) != HF_MAX_CODE_LEN) return HF_ERR_CORRUPT;
+    // (a version-1 blob is dense and has zeros where version 2 keeps its two fields; a dense
+    // stream is never written as version 2)
+    const uint32_t placement = version == 1 ? (uint32_t)HF_PLACEMENT_DENSE : get32(h + 104);
+    if (version == 2 && placement == HF_PLACEMENT_DENSE) return HF_ERR_CORRUPT;
     hf_container_info pl;
-    if (!plan_container(get64(h + 40), (int)get32(h + 16), (int)get32(h + 20), get64(h + 56), &pl))
+    if (!plan_container(get64(h + 40), (int)get32(h + 16), (int)get32(h + 20), (int)placement,
+                        get64(h + 56), &pl))
         return HF_ERR_CORRUPT;
     if (get64(h + 48) != pl.nchunks || get64(h + 64) != pl.off_codebook ||
         get64(h + 72) != pl.off_chunk_off || get64(h + 80) != pl.off_side ||
         get64(h + 88) != pl.off_payload || get64(h + 96) != pl.total_bytes ||
         pl.total_bytes > blob_bytes)
         return HF_ERR_CORRUPT;
-    for (int i = 104; i < HF_CONTAINER_HEADER_BYTES; ++i)
+    if (version == 2 && (get64(h + 112) != pl.off_chunk_words || get32(h + 108) != 0))
+        return HF_ERR_CORRUPT;
+    for (int i = version == 2 ? 120 : 104; i < HF_CONTAINER_HEADER_BYTES; ++i)
         if (h[i] != 0) return HF_ERR_CORRUPT;
     pl.mode = get32(h + 32);
     pl.entropy_q16 = get32(h + 36);
@@ -1273,13 +1321,15 @@ int hf_container_open(hf_ctx* ctx, const void* d_blob, uint64_t blob_bytes,
 
 int hf_container_codebook(hf_ctx* ctx, const void* d_blob, const hf_container_info* info,
                           void* d_codebook_out) {
-    if (!ctx || !d_blob || !info || !d_codebook_out) return HF_ERR_ARG;
+    if (!ctx || !d_blob || !info) return HF_ERR_ARG;
     if (!aligned16(d_blob) || !aligned16(d_codebook_out)) return HF_ERR_ALIGN;
     hf_container_info pl;
-    if (!plan_container(info->n, (int)info->layout, (int)info->codebook_kind, info->payload_words,
-                        &pl) ||
+    if (!plan_container(info->n, (int)info->layout, (int)info->codebook_kind, (int)info->placement,
+                        info->payload_words, &pl) ||
         pl.off_codebook != info->off_codebook)
         return HF_ERR_ARG;
+    if (pl.placement == HF_PLACEMENT_PAGED) return HF_OK;  // the records are in the pages
+    if (!d_codebook_out) return HF_ERR_ARG;
     HF_USE_DEVICE(ctx);
     const uint8_t* blob = reinterpret_cast<const uint8_t*>(d_blob);
     if (pl.codebook_kind == HF_CODEBOOK_STREAM) {

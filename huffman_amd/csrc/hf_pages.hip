@@ -448,8 +448,10 @@ struct DecPageLds {
     uint8_t r2s[256];
     uint32_t present[8];
     uint32_t cls[20];  // [d]: ranks with codes of at most d bits << 17 | their share of the code space
+    // first bit of region r ([128] = the sum of the region lengths); once every thread has taken
+    // its two values (before the last barrier in front of the symbol loop) the backward strings'
+    // bit counts are handed to the forward ones through the same words
     uint32_t rstart[132];
-    uint32_t used[256];
     uint32_t red[8];
 };
 
@@ -486,39 +488,43 @@ struct PageTables {
     }
 };
 
-// One lane's walk through its own string.  The window is two registers (hi: the next 32 bits, MSB
-// first; lo: what is buffered behind them) and a count of buffered bits; before a pair of symbols a
-// lane holding fewer than 32 bits takes its next word, which was requested a pair earlier, so the
-// word's LDS latency lies beside the pair's two table lookups and not in front of them.  Inside a
-// pair only `hi` moves (32-bit shifts: 32 valid bits cover two codes); the 64-bit shift happens once
-// per pair.  Backward strings walk down through the words and take each word bit-reversed.
+// One lane's walk through its own string.  The lane keeps two consecutive words of the string (wc,
+// wx) and the number s of bits of wx that do NOT yet belong to the next 32: those 32 bits are one
+// funnel shift of the pair, ({wc, wx} >> s), with s in 0..31 (s = 0: wc is used up and the bits are
+// wx itself, which is why the count runs 1..32 bits of wc consumed and never 0).  A pair of symbols
+// takes at most 32 bits, so after it at most one new word moves in -- wc = wx, wx = the word that was
+// requested a pair earlier, whose LDS latency thus lies beside the two table lookups and not in
+// front of them.  No 64-bit shifts, no window to refill.  Inside a pair the second lookup shifts
+// the 32 bits alone (at least 16 of them remain).  Backward strings walk down through the words
+// and take each word bit-reversed.
 //
-// the 64 symbols of string (q, lane) of a full page whose image is in LDS; returns the bits consumed
+// The 64 symbols of string (q, lane) of a full page whose image is in LDS.  bitpos: forward, the
+// string's first bit; backward, the bit behind its first one (the region's end).  Returns the bits
+// consumed.
 template <int LAYOUT, bool BACK, class TAB>
 __device__ __forceinline__ uint32_t decode_string(const uint32_t img_str_addr, const uint32_t bitpos,
                                                   const uint32_t q, const int lane, const TAB& T,
                                                   const uint8_t* __restrict__ side_chunk,
                                                   void* __restrict__ out_chunk, uint32_t* err) {
-    // forward: bitpos = the string's first bit; backward: its first bit too, the region's last
-    const uint32_t wi = img_str_addr + (bitpos >> 5) * 4u;
-    const uint32_t sh = BACK ? 31u - (bitpos & 31u) : (bitpos & 31u);
-    uint32_t hi, lo, wp;
-    {
-        u64 win;
-        if (BACK) {
-            win = ((u64)__builtin_bitreverse32(lds_u32(wi)) << 32) |
-                  (u64)__builtin_bitreverse32(lds_u32(wi - 4u));
-            wp = wi - 8u;
-        } else {
-            win = ((u64)lds_u32(wi) << 32) | (u64)lds_u32(wi + 4u);
-            wp = wi + 8u;
-        }
-        win <<= sh;
-        hi = (uint32_t)(win >> 32);
-        lo = (uint32_t)win;
+    uint32_t wc, wx, wp;
+    int s;
+    if (BACK) {
+        const uint32_t a = img_str_addr + (bitpos >> 5) * 4u;
+        s = (int)(bitpos & 31u);
+        wc = __builtin_bitreverse32(lds_u32(a));
+        wx = __builtin_bitreverse32(lds_u32(a - 4u));
+        wp = a - 8u;
+    } else {
+        const int before = (int)bitpos - 1;  // (-1: the word in front of the strings, never used)
+        const uint32_t a = img_str_addr + (uint32_t)((before >> 5) * 4);
+        s = (int)(~(uint32_t)before & 31u);
+        wc = lds_u32(a);
+        wx = lds_u32(a + 4u);
+        wp = a + 8u;
     }
-    uint32_t nb = 64u - sh;         // buffered bits
-    uint32_t wnext = lds_u32(wp);  // the next word, requested ahead
+    const uint32_t wp0 = wp;
+    const int s0 = s;
+    uint32_t wn = lds_u32(wp);  // the next word, requested ahead
     const hf_gmem_u8* const su = hf_uniform_ptr(side_chunk);
     hf_gmem_u8* const ou = hf_uniform_ptr(out_chunk);
     const uint32_t lane8 = (uint32_t)lane * 8u, lane16 = (uint32_t)lane * 16u;
@@ -543,15 +549,7 @@ __device__ __forceinline__ uint32_t decode_string(const uint32_t img_str_addr, c
         uint32_t e[8];
 #pragma unroll
         for (int jp = 0; jp < 4; ++jp) {
-            if (nb < 32u) {
-                // fewer than 32 bits: they all sit in hi, lo is empty, and the word goes behind them
-                const uint32_t w = BACK ? __builtin_bitreverse32(wnext) : wnext;
-                hi |= w >> nb;
-                lo = __builtin_amdgcn_alignbit(w, 0u, nb);
-                nb |= 32u;
-                wp += BACK ? (uint32_t)-4 : 4u;
-            }
-            wnext = lds_u32(wp);
+            const uint32_t hi = __builtin_amdgcn_alignbit(wc, wx, (uint32_t)s);
             // (a first-level entry of 0 is a longer code: a lane that met one has not moved, its
             // second lookup returns the same entry, and one test can cover both)
             uint32_t e0 = T.lookup(hi), e1;
@@ -574,11 +572,14 @@ __device__ __forceinline__ uint32_t decode_string(const uint32_t img_str_addr, c
             }
             e[2 * jp] = e0;
             e[2 * jp + 1] = e1;
-            const uint32_t cl = (e0 & 0xFFu) + (e1 & 0xFFu);  // 2 .. 32
-            const u64 win = (((u64)hi << 32) | (u64)lo) << cl;
-            hi = (uint32_t)(win >> 32);
-            lo = (uint32_t)win;
-            nb -= cl;
+            s -= (int)((e0 & 0xFFu) + (e1 & 0xFFu));  // 2 .. 32 bits
+            if (s < 0) {
+                wc = wx;
+                wx = BACK ? __builtin_bitreverse32(wn) : wn;
+                s += 32;
+                wp += BACK ? (uint32_t)-4 : 4u;
+                wn = lds_u32(wp);
+            }
         }
         if (LAYOUT == HF_LAYOUT_BF16_EXP) {
             // two bf16 per dword (see decode_chunk_full in hf_decode.hip)
@@ -603,9 +604,9 @@ __device__ __forceinline__ uint32_t decode_string(const uint32_t img_str_addr, c
                                         reinterpret_cast<hf_gmem_u32x2*>(ou + r * 512u + lane8));
         }
     }
-    // words taken x 32, less what is still buffered, less the bits skipped in the first word
-    const uint32_t taken = BACK ? (wi + 4u - wp) / 4u - 1u : (wp - wi) / 4u;
-    return taken * 32u - nb - sh;
+    // 32 bits per word moved in, and what the count of unused bits of wx lost
+    const uint32_t moved = (BACK ? wp0 - wp : wp - wp0) / 4u;
+    return moved * 32u + (uint32_t)(s0 - s);
 }
 
 // The same for pages that are not full or whose strings stayed in global memory: symbol by symbol,
@@ -826,8 +827,11 @@ __global__ __launch_bounds__(256) void hf_k_decode_pages(
         T.cls_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(L.cls));
         T.r2s_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(L.r2s));
     }
+    const uint32_t r = (q & 1u) * 64u + (uint32_t)lane;
+    const uint32_t s0 = L.rstart[r], s1 = L.rstart[r + 1];
+    const bool sums = L.rstart[128] == B;
     __syncthreads();
-    if (L.rstart[128] != B) return bad();  // the regions do not add up to the page's bits
+    if (!sums) return bad();  // the regions do not add up to the page's bits
 
     // ---- the four sub-decoders ----
     const size_t elem_bytes = LAYOUT == HF_LAYOUT_BF16_EXP ? 2 : 1;
@@ -835,8 +839,6 @@ __global__ __launch_bounds__(256) void hf_k_decode_pages(
     const uint64_t out_first = page_ids ? (uint64_t)slot * HF_CHUNK_SYMS : first;
     void* out_chunk = reinterpret_cast<uint8_t*>(out) + out_first * elem_bytes;
     const uint32_t hdr_words = kHdr + hw + kGap;
-    const uint32_t r = (q & 1u) * 64u + (uint32_t)lane;
-    const uint32_t s0 = L.rstart[r], s1 = L.rstart[r + 1];
     uint32_t used;
     // (a full page's strings have 64 bits at least; a region shorter than two of them is damage,
     // and the whole wavefront then goes the careful way)
@@ -846,7 +848,7 @@ __global__ __launch_bounds__(256) void hf_k_decode_pages(
         if (q < 2)
             used = decode_string<LAYOUT, false>(str_addr, s0, q, lane, T, side_chunk, out_chunk, err);
         else
-            used = decode_string<LAYOUT, true>(str_addr, s1 - 1u, q, lane, T, side_chunk, out_chunk, err);
+            used = decode_string<LAYOUT, true>(str_addr, s1, q, lane, T, side_chunk, out_chunk, err);
     } else {
         const uint32_t wn = (B + 31u) / 32u;
         const uint32_t* gstr = payload + off0 + hdr_words;
@@ -862,10 +864,10 @@ __global__ __launch_bounds__(256) void hf_k_decode_pages(
         used = decode_string_slow<LAYOUT>(back, back ? s1 - 1u : s0, empty || s1 == s0, q, lane, nvalid, T,
                                           word, side_chunk, out_chunk, err);
     }
-    L.used[tid] = used;
+    if (q >= 2) L.rstart[tid - 128] = used;
     __syncthreads();
     // the two strings of a region meet exactly
-    if (q < 2 && L.used[tid] + L.used[tid + 128] != R) atomicOr(err, HF_KERR_CORRUPT);
+    if (q < 2 && used + L.rstart[tid] != R) atomicOr(err, HF_KERR_CORRUPT);
 }
 
 }  // namespace

@@ -314,8 +314,8 @@ int hf_decode_chunks_to(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload
  * nchunks + 1 values, the last one the stream's words), d_chunk_words[c] = words the chunk filled;
  * the rest of a slot is zero.  The payload is 1.5-3 % larger than the dense one (about 54 words per
  * full chunk) and is written without staging or look-back, at 1.1-1.45x the dense encoder's rate.
- * It is not a format-v1 payload: hf_container_pack does not take it, and it is decoded by
- * hf_decode_chunks_slotted only.  payload_cap_words >= hf_slotted_bound_words(n) always fits; a
+ * It is not a dense payload: it is decoded by hf_decode_chunks_slotted only, and stored as a
+ * version-2 container with its words array (hf_container_pack_placed).  payload_cap_words >= hf_slotted_bound_words(n) always fits; a
  * smaller buffer that the slots do not fit gives HF_ERR_OVERFLOW and nothing is written.
  * Histograms that are not this data's give HF_ERR_CORRUPT (a chunk outgrew its slot; nothing is
  * written outside the slot).  No counterpart in the reference (its top level stops at the
@@ -412,32 +412,41 @@ int hf_chunk_codebook_download(hf_ctx* ctx, const void* d_chunk_codebooks, uint6
 
 /* ---- container: one self-describing blob per encoded stream --------------------------------
  * The reference stops at one {code, length, mode} beat per symbol (top_encoder.scala:17-21) and
- * defines no stored form; this is the wire format of this library (version 1, little endian).
+ * defines no stored form; this is the wire format of this library (little endian).  Version 1
+ * holds dense streams (hf_encode, hf_encode_chunks); version 2 adds the other two placements, the
+ * slotted one (hf_encode_slotted, hf_encode_chunks_slotted) and the paged one (hf_encode_pages).
+ * A dense stream is always written as version 1; both versions are read.
  *
  *   header, HF_CONTAINER_HEADER_BYTES = 128:
  *     0 magic "HUFHIP1\0" | 8 u32 version | 12 u32 header_bytes | 16 u32 layout |
  *     20 u32 codebook_kind | 24 u32 chunk_syms | 28 u32 max_code_len | 32 u32 mode |
  *     36 u32 entropy_q16 | 40 u64 n | 48 u64 nchunks | 56 u64 payload_words |
  *     64 u64 off_codebook | 72 u64 off_chunk_off | 80 u64 off_side | 88 u64 off_payload |
- *     96 u64 total_bytes | 104..127 zero
+ *     96 u64 total_bytes | version 2: 104 u32 placement | 108 zero | 112 u64 off_chunk_words |
+ *     otherwise zero up to 127
  *   sections, each starting on a 16-byte boundary, zero padded, in this order:
  *     codebook   HF_CODEBOOK_STREAM: code u16[256], length u8[256] (768 bytes);
  *                HF_CODEBOOK_PER_CHUNK: nchunks records of HF_CONTAINER_CHUNK_CODEBOOK_BYTES:
  *                rank2sym u8[256] (symbols in (count desc, symbol asc) order), u16[16] number of
  *                ranks with code length 1..16 (lengths never decrease with rank, codes are
- *                canonical in rank order), u32 mode, u32 entropy_q16
- *     chunk_off  u32[nchunks + 1]
+ *                canonical in rank order), u32 mode, u32 entropy_q16;
+ *                absent (off_codebook = 0) for HF_PLACEMENT_PAGED: the records are in the pages
+ *     chunk_off  u32[nchunks + 1]: first words of the chunks / slots / pages, then the total
+ *     chunk_words  HF_PLACEMENT_SLOTTED only: u32[nchunks], the words each chunk fills of its slot
  *     side       HF_LAYOUT_BF16_EXP: u8[n]; HF_LAYOUT_FP16_EXP, _FP8_E4M3_EXP, _FP4_E2M1_EXP: the packed
  *                side fields, hf_fields_side_bytes(n, layout) bytes (the payload then codes the
  *                symbol bytes of hf_fields_split); absent otherwise
  *     payload    u32[payload_words], padded to at least 16 bytes
- * Every section can be handed to hf_decode / hf_decode_chunks in place (d_blob + offset), so a
- * stored stream is decoded, whole or block by block, without unpacking it. */
-#define HF_CONTAINER_VERSION 1
+ * Every section can be handed to the decoders in place (d_blob + offset), so a stored stream is
+ * decoded, whole or block by block, without unpacking it. */
+#define HF_CONTAINER_VERSION 2
 #define HF_CONTAINER_HEADER_BYTES 128
 #define HF_CONTAINER_CHUNK_CODEBOOK_BYTES 296
 #define HF_CODEBOOK_STREAM 0
 #define HF_CODEBOOK_PER_CHUNK 1
+#define HF_PLACEMENT_DENSE 0   /* chunks back to back (hf_encode, hf_encode_chunks)          */
+#define HF_PLACEMENT_SLOTTED 1 /* chunks in slots, with chunk_words                          */
+#define HF_PLACEMENT_PAGED 2   /* self-contained pages (hf_encode_pages), HF_CODEBOOK_PER_CHUNK */
 
 typedef struct hf_container_info {
     uint32_t version;
@@ -447,33 +456,44 @@ typedef struct hf_container_info {
     uint32_t max_code_len;
     uint32_t mode;        /* stream-wide codebook: compression_mode; per chunk: in the records */
     uint32_t entropy_q16; /* stream-wide codebook only */
-    uint32_t reserved;
+    uint32_t placement;   /* HF_PLACEMENT_* */
     uint64_t n;
     uint64_t nchunks;
     uint64_t payload_words;
-    uint64_t off_codebook;
+    uint64_t off_codebook; /* 0 when the pages carry the records */
     uint64_t off_chunk_off;
     uint64_t off_side; /* 0 when there is no side stream */
     uint64_t off_payload;
     uint64_t total_bytes;
+    uint64_t off_chunk_words; /* 0 unless slotted */
 } hf_container_info;
 
-/* Section offsets and the total size for a stream of n symbols (host arithmetic only). */
+/* Section offsets and the total size for a stream of n symbols (host arithmetic only);
+ * hf_container_plan is hf_container_plan_placed with HF_PLACEMENT_DENSE. */
 int hf_container_plan(uint64_t n, int layout, int codebook_kind, uint64_t payload_words,
                       hf_container_info* info);
-/* Write the blob: header from `info` (as filled by hf_container_plan; mode / entropy are taken
- * from the device codebook), codebook(s) in wire form, offsets, side bytes, payload.  All
- * pointers are device pointers; d_codebook is an HF_CODEBOOK_DEV_BYTES codebook or an array of
- * HF_CHUNK_CODEBOOK_BYTES records according to info->codebook_kind.  Synchronises. */
+int hf_container_plan_placed(uint64_t n, int layout, int codebook_kind, int placement,
+                             uint64_t payload_words, hf_container_info* info);
+/* Write the blob: header from `info` (as filled by a plan call; mode / entropy are taken from the
+ * device codebook), codebook(s) in wire form, offsets, side bytes, payload.  All pointers are
+ * device pointers; d_codebook is an HF_CODEBOOK_DEV_BYTES codebook or an array of
+ * HF_CHUNK_CODEBOOK_BYTES records according to info->codebook_kind (not used, may be NULL, for a
+ * paged stream); d_chunk_words only for a slotted one.  hf_container_pack is the same without
+ * d_chunk_words (dense and paged streams).  Synchronises. */
 int hf_container_pack(hf_ctx* ctx, hf_container_info* info, const void* d_codebook,
                       const uint32_t* d_chunk_off, const uint8_t* d_side,
                       const uint32_t* d_payload, void* d_blob, uint64_t blob_cap_bytes);
+int hf_container_pack_placed(hf_ctx* ctx, hf_container_info* info, const void* d_codebook,
+                             const uint32_t* d_chunk_off, const uint32_t* d_chunk_words,
+                             const uint8_t* d_side, const uint32_t* d_payload, void* d_blob,
+                             uint64_t blob_cap_bytes);
 /* Read and validate the header of a blob in device memory (HF_ERR_CORRUPT if it is not a
- * version-1 container that fits blob_bytes).  Synchronises. */
+ * version-1 or version-2 container that fits blob_bytes).  Synchronises. */
 int hf_container_open(hf_ctx* ctx, const void* d_blob, uint64_t blob_bytes,
                       hf_container_info* info);
 /* Rebuild the device codebook(s) of an opened blob into d_codebook_out (HF_CODEBOOK_DEV_BYTES,
- * or nchunks * HF_CHUNK_CODEBOOK_BYTES for per-chunk codebooks).  Synchronises. */
+ * or nchunks * HF_CHUNK_CODEBOOK_BYTES for per-chunk codebooks; nothing to do, and
+ * d_codebook_out may be NULL, for a paged stream).  Synchronises. */
 int hf_container_codebook(hf_ctx* ctx, const void* d_blob, const hf_container_info* info,
                           void* d_codebook_out);
 

@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--pages", type=int, default=1 << 16)
     ap.add_argument("--kind", default="fp8")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--no-read", action="store_true", help="skip the decode-on-read batches")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     t = make(a.kind, a.pages, dev)
@@ -107,7 +108,7 @@ def main():
             alg = n * eb + 4.0 * words[kind]
         print(f"  {k:12s} {v:8.3f} ms  {n * eb / v / 1e6:8.0f} GB/s of input  "
               f"{alg / v / 1e6 / 8000:6.3f} of peak (algorithmic bytes)")
-    if lay != 0:
+    if lay != 0 or a.no_read:
         return
     pool_pages = min(1 << 15, pages)
     pool = torch.empty(pool_pages * CH, dtype=torch.uint8, device=dev)
