@@ -138,8 +138,13 @@ trait HuffHip extends Library {
   // container (stored form; no counterpart in the reference)
   def hf_container_plan(n: Long, layout: Int, codebookKind: Int, payloadWords: Long,
                         info: ContainerInfo): Int
+  def hf_container_plan_placed(n: Long, layout: Int, codebookKind: Int, placement: Int,
+                               payloadWords: Long, info: ContainerInfo): Int
   def hf_container_pack(ctx: Pointer, info: ContainerInfo, dCodebook: Pointer, dChunkOff: Pointer,
                         dSide: Pointer, dPayload: Pointer, dBlob: Pointer, blobCap: Long): Int
+  def hf_container_pack_placed(ctx: Pointer, info: ContainerInfo, dCodebook: Pointer,
+                               dChunkOff: Pointer, dChunkWords: Pointer, dSide: Pointer,
+                               dPayload: Pointer, dBlob: Pointer, blobCap: Long): Int
   def hf_container_open(ctx: Pointer, dBlob: Pointer, blobBytes: Long, info: ContainerInfo): Int
   def hf_container_codebook(ctx: Pointer, dBlob: Pointer, info: ContainerInfo,
                             dCodebookOut: Pointer): Int
@@ -153,12 +158,12 @@ trait HuffHip extends Library {
 }
 
 @Structure.FieldOrder(Array("version", "layout", "codebook_kind", "chunk_syms", "max_code_len",
-  "mode", "entropy_q16", "reserved", "n", "nchunks", "payload_words", "off_codebook",
-  "off_chunk_off", "off_side", "off_payload", "total_bytes"))
+  "mode", "entropy_q16", "placement", "n", "nchunks", "payload_words", "off_codebook",
+  "off_chunk_off", "off_side", "off_payload", "total_bytes", "off_chunk_words"))
 class ContainerInfo extends Structure {
-  var version, layout, codebook_kind, chunk_syms, max_code_len, mode, entropy_q16, reserved: Int = 0
+  var version, layout, codebook_kind, chunk_syms, max_code_len, mode, entropy_q16, placement: Int = 0
   var n, nchunks, payload_words, off_codebook, off_chunk_off, off_side, off_payload,
-      total_bytes: Long = 0L
+      total_bytes, off_chunk_words: Long = 0L
 }
 
 @Structure.FieldOrder(Array("encoding_mode", "tree_depth_limit", "min_freq_threshold"))
@@ -169,6 +174,7 @@ class EntropyConfig extends Structure {
 object HuffHip { lazy val lib: HuffHip = Native.load("huffhip", classOf[HuffHip]) }
 
 // HF_RESERVE_*, HF_LAYOUT_* and HF_MODE_* of include/huffhip.h
+object Placement { val DENSE = 0; val SLOTTED = 1; val PAGED = 2 }
 object Reserve {
   val ENCODE = 1; val CODEBOOKS = 2; val PLACED = 4; val ALL = 7
 }

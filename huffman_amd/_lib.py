@@ -28,10 +28,11 @@ HF_MODE_BYPASS, HF_MODE_HUFFMAN, HF_MODE_AUTO, HF_MODE_BEST = 0, 1, 2, 3
 HF_CODEBOOK_DEV_BYTES = 36864
 HF_CHUNK_CODEBOOK_BYTES = 1552
 HF_STATIC_CB_MAX_CHUNKS = 4096
-HF_CONTAINER_VERSION = 1
+HF_CONTAINER_VERSION = 2
 HF_CONTAINER_HEADER_BYTES = 128
 HF_CONTAINER_CHUNK_CODEBOOK_BYTES = 296
 HF_CODEBOOK_STREAM, HF_CODEBOOK_PER_CHUNK = 0, 1
+HF_PLACEMENT_DENSE, HF_PLACEMENT_SLOTTED, HF_PLACEMENT_PAGED = 0, 1, 2
 HF_RESERVE_ENCODE, HF_RESERVE_CODEBOOKS, HF_RESERVE_PLACED, HF_RESERVE_ALL = 1, 2, 4, 7
 HF_PAGE_HDR_WORDS, HF_PAGE_GAP_WORDS = 10, 48
 
@@ -63,10 +64,10 @@ class hf_container_info(C.Structure):
     _fields_ = [
         ("version", C.c_uint32), ("layout", C.c_uint32), ("codebook_kind", C.c_uint32),
         ("chunk_syms", C.c_uint32), ("max_code_len", C.c_uint32), ("mode", C.c_uint32),
-        ("entropy_q16", C.c_uint32), ("reserved", C.c_uint32),
+        ("entropy_q16", C.c_uint32), ("placement", C.c_uint32),
         ("n", C.c_uint64), ("nchunks", C.c_uint64), ("payload_words", C.c_uint64),
         ("off_codebook", C.c_uint64), ("off_chunk_off", C.c_uint64), ("off_side", C.c_uint64),
-        ("off_payload", C.c_uint64), ("total_bytes", C.c_uint64),
+        ("off_payload", C.c_uint64), ("total_bytes", C.c_uint64), ("off_chunk_words", C.c_uint64),
     ]
 
 
@@ -138,8 +139,12 @@ SIGNATURES = {
     "hf_chunk_codebook_download": (C.c_int, [_vp, _vp, C.c_uint64, _u16p, _u8p, _ip, _u32p]),
     "hf_container_plan": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_uint64,
                                     C.POINTER(hf_container_info)]),
+    "hf_container_plan_placed": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_uint64,
+                                           C.POINTER(hf_container_info)]),
     "hf_container_pack": (C.c_int, [_vp, C.POINTER(hf_container_info), _vp, _vp, _vp, _vp, _vp,
                                     C.c_uint64]),
+    "hf_container_pack_placed": (C.c_int, [_vp, C.POINTER(hf_container_info), _vp, _vp, _vp, _vp,
+                                           _vp, _vp, C.c_uint64]),
     "hf_container_open": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(hf_container_info)]),
     "hf_container_codebook": (C.c_int, [_vp, _vp, C.POINTER(hf_container_info), _vp]),
     "hf_quality": (C.c_int, [_vp, _u64p, _u8p, C.c_int, C.c_int, _u16p, _u16p, _u16p]),

@@ -414,63 +414,79 @@ class EncodedStream:
     def ratio(self) -> float:
         return self.n * element_bytes(self.layout) / max(1, self.compressed_bytes())
 
-    # -- container (wire format v1, include/huffhip.h) ---------------------------------------------
+    # -- container (wire format, include/huffhip.h) ------------------------------------------------
+    @property
+    def placement(self) -> int:
+        return L.HF_PLACEMENT_PAGED if self.paged else (
+            L.HF_PLACEMENT_SLOTTED if self.chunk_words is not None else L.HF_PLACEMENT_DENSE)
+
+    def _plan(self):
+        assert self.total_words is not None, "encode with sync=True first"
+        info = L.hf_container_info()
+        per_chunk = self.chunk_codebooks is not None or self.paged
+        check(L.lib().hf_container_plan_placed(self.n, self.layout, 1 if per_chunk else 0,
+                                               self.placement, self.total_words, C.byref(info)),
+              "hf_container_plan_placed")
+        return info, per_chunk
+
     def container_bytes(self) -> int:
         """Size of this stream's container (host arithmetic, nothing is packed)."""
-        assert self.total_words is not None, "encode with sync=True first"
-        if self.chunk_words is not None or self.paged:
-            raise ValueError("a slotted stream is not a format-v1 payload: no container")
-        info = L.hf_container_info()
-        check(L.lib().hf_container_plan(self.n, self.layout,
-                                        1 if self.chunk_codebooks is not None else 0,
-                                        self.total_words, C.byref(info)), "hf_container_plan")
-        return int(info.total_bytes)
+        return int(self._plan()[0].total_bytes)
 
     def to_container(self, ctx: Optional["Context"] = None) -> torch.Tensor:
-        """One self-describing uint8 device tensor: header, codebook(s), chunk offsets, side
-        bytes, payload."""
-        assert self.total_words is not None, "encode with sync=True first"
-        if self.chunk_words is not None:
-            raise ValueError("a slotted stream is not a format-v1 payload: no container")
+        """One self-describing uint8 device tensor: header, codebook(s), chunk offsets, the words
+        array of a slotted stream, side bytes, payload.  Dense streams are written as wire format
+        version 1, slotted and paged ones as version 2."""
         ctx = ctx if ctx is not None else default_context()
-        per_chunk = self.chunk_codebooks is not None
-        info = L.hf_container_info()
-        check(L.lib().hf_container_plan(self.n, self.layout, 1 if per_chunk else 0,
-                                        self.total_words, C.byref(info)), "hf_container_plan")
+        info, per_chunk = self._plan()
         blob = torch.empty(int(info.total_bytes), dtype=torch.uint8, device=self.payload.device)
-        cb_ptr = self.chunk_codebooks.data_ptr() if per_chunk else self.codebook.ptr
-        check(L.lib().hf_container_pack(ctx.handle, C.byref(info), C.c_void_p(cb_ptr),
-                                        C.c_void_p(self.chunk_off.data_ptr()),
-                                        C.c_void_p(_dev_ptr(self.side)),
-                                        C.c_void_p(self.payload.data_ptr()),
-                                        C.c_void_p(blob.data_ptr()), blob.numel()),
-              "hf_container_pack")
+        if self.paged:
+            cb_ptr = 0
+        else:
+            cb_ptr = self.chunk_codebooks.data_ptr() if per_chunk else self.codebook.ptr
+        check(L.lib().hf_container_pack_placed(ctx.handle, C.byref(info), C.c_void_p(cb_ptr),
+                                               C.c_void_p(self.chunk_off.data_ptr()),
+                                               C.c_void_p(_dev_ptr(self.chunk_words)),
+                                               C.c_void_p(_dev_ptr(self.side)),
+                                               C.c_void_p(self.payload.data_ptr()),
+                                               C.c_void_p(blob.data_ptr()), blob.numel()),
+              "hf_container_pack_placed")
         return blob
 
     @staticmethod
     def from_container(blob: torch.Tensor, dtype: Optional[torch.dtype] = None,
                        ctx: Optional["Context"] = None) -> "EncodedStream":
         """Open a container in device memory.  The stream's payload, offsets and side bytes are
-        views into ``blob`` (nothing is copied); only the codebook tables are rebuilt."""
+        views into ``blob`` (nothing is copied); only the codebook tables are rebuilt (a paged
+        stream has none outside its pages)."""
         assert blob.dtype == torch.uint8 and blob.is_cuda and blob.is_contiguous()
         ctx = ctx if ctx is not None else default_context()
         info = L.hf_container_info()
         check(L.lib().hf_container_open(ctx.handle, C.c_void_p(blob.data_ptr()), blob.numel(),
                                         C.byref(info)), "hf_container_open")
         n, nch, words = int(info.n), int(info.nchunks), int(info.payload_words)
+        paged = info.placement == L.HF_PLACEMENT_PAGED
         per_chunk = info.codebook_kind == L.HF_CODEBOOK_PER_CHUNK
-        if per_chunk:
+        cbs, cb, cb_ptr = None, None, 0
+        if paged:
+            pass
+        elif per_chunk:
             cbs = torch.empty(max(1, nch) * L.HF_CHUNK_CODEBOOK_BYTES, dtype=torch.uint8,
                               device=blob.device)
-            cb, cb_ptr = None, cbs.data_ptr()
+            cb_ptr = cbs.data_ptr()
         else:
-            cbs, cb = None, DeviceCodebook(ctx)
+            cb = DeviceCodebook(ctx)
             cb_ptr = cb.ptr
         check(L.lib().hf_container_codebook(ctx.handle, C.c_void_p(blob.data_ptr()),
                                             C.byref(info), C.c_void_p(cb_ptr)),
               "hf_container_codebook")
         o_off, o_side, o_pay = int(info.off_chunk_off), int(info.off_side), int(info.off_payload)
         chunk_off = blob[o_off:o_off + 4 * (nch + 1)].view(torch.int32)
+        chunk_words = None
+        if info.placement == L.HF_PLACEMENT_SLOTTED:
+            o_w = int(info.off_chunk_words)
+            # (padded to its 16-byte boundary: the decoders want aligned arrays, whatever nch is)
+            chunk_words = blob[o_w:o_w + 4 * (((nch + 3) // 4) * 4)].view(torch.int32)
         nside = side_bytes(n, int(info.layout))
         side = blob[o_side:o_side + nside] if o_side else None
         payload = blob[o_pay:int(info.total_bytes)].view(torch.int32)  # padded to >= 4 words
@@ -479,7 +495,7 @@ class EncodedStream:
                      HF_LAYOUT_FP16_EXP: torch.float16}.get(int(info.layout), torch.uint8)
         return EncodedStream(n=n, layout=int(info.layout), dtype=dtype, payload=payload,
                              chunk_off=chunk_off, side=side, codebook=cb, total_words=words,
-                             chunk_codebooks=cbs)
+                             chunk_codebooks=cbs, chunk_words=chunk_words, paged=paged)
 
 
 class EntropyAwareHuffmanSystem(_Module):

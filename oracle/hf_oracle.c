@@ -1101,3 +1101,104 @@ int orc_rp_decode_pages(const uint32_t* payload, const uint32_t* page_off, size_
     free(tab);
     return rc;
 }
+
+/* ---- container, wire format version 2 ------------------------------------------------------
+ * Version 1 plus a placement field and, for slotted streams, the words array: header bytes 104
+ * (u32 placement: 1 slotted, 2 paged), 108 (zero), 112 (u64 offset of the words array, 0 unless
+ * slotted).  Sections: codebook (as version 1; absent, offset 0, for a paged stream, whose pages
+ * carry the records), chunk offsets, chunk words (slotted only, u32[nchunks]), side bytes,
+ * payload.  A dense stream (placement 0) is always a version-1 container. */
+static void container2_offsets(uint64_t n, int layout, int kind, int placement, uint64_t payload_words,
+                               uint64_t off[5], uint64_t* total) {
+    const uint64_t nchunks = orc_num_chunks((size_t)n);
+    uint64_t at = 128;
+    off[0] = 0;
+    if (placement != 2) {
+        off[0] = at;
+        at = round16(at + (kind == 0 ? 768u : nchunks * 296u));
+    }
+    off[1] = at;
+    at = round16(at + 4u * (nchunks + 1));
+    off[4] = 0;
+    if (placement == 1) {
+        off[4] = at;
+        at = round16(at + 4u * nchunks);
+    }
+    off[2] = 0;
+    if (orc_side_bytes(n, layout) != 0 || layout == ORC_LAYOUT_BF16_EXP) {
+        off[2] = at;
+        at = round16(at + orc_side_bytes(n, layout));
+    }
+    off[3] = at;
+    at += payload_words * 4u < 16u ? 16u : round16(payload_words * 4u);
+    *total = at;
+}
+
+uint64_t orc_container2_bytes(uint64_t n, int layout, int kind, int placement, uint64_t payload_words) {
+    uint64_t off[5], total;
+    container2_offsets(n, layout, kind, placement, payload_words, off, &total);
+    return total;
+}
+
+uint64_t orc_container2_pack(uint8_t* out, uint64_t n, int layout, int kind, int placement,
+                             uint64_t payload_words, uint32_t mode, uint32_t entropy_q16,
+                             const uint16_t* code, const uint8_t* len, const uint8_t* rank2sym,
+                             const uint8_t* len_by_rank, const uint32_t* modes,
+                             const uint32_t* entropies, const uint32_t* chunk_off,
+                             const uint32_t* chunk_words, const uint8_t* side,
+                             const uint32_t* payload) {
+    if (placement == 0)
+        return orc_container_pack(out, n, layout, kind, payload_words, mode, entropy_q16, code, len,
+                                  rank2sym, len_by_rank, modes, entropies, chunk_off, side, payload);
+    uint64_t off[5], total;
+    container2_offsets(n, layout, kind, placement, payload_words, off, &total);
+    const uint64_t nchunks = orc_num_chunks((size_t)n);
+    memset(out, 0, (size_t)total);
+    memcpy(out, "HUFHIP1", 8);
+    le32(out + 8, 2);
+    le32(out + 12, 128);
+    le32(out + 16, (uint32_t)layout);
+    le32(out + 20, (uint32_t)kind);
+    le32(out + 24, ORC_CHUNK_SYMS);
+    le32(out + 28, 16);
+    le32(out + 32, kind == 0 ? mode : 0xFFFFFFFFu);
+    le32(out + 36, kind == 0 ? entropy_q16 : 0u);
+    le64(out + 40, n);
+    le64(out + 48, nchunks);
+    le64(out + 56, payload_words);
+    for (int i = 0; i < 4; ++i) le64(out + 64 + 8 * i, off[i]);
+    le64(out + 96, total);
+    le32(out + 104, (uint32_t)placement);
+    le64(out + 112, off[4]);
+    if (off[0]) {
+        uint8_t* p = out + off[0];
+        if (kind == 0) {
+            for (int s = 0; s < 256; ++s) {
+                p[2 * s] = (uint8_t)(code[s] & 0xFF);
+                p[2 * s + 1] = (uint8_t)(code[s] >> 8);
+                p[512 + s] = len[s];
+            }
+        } else {
+            for (uint64_t c = 0; c < nchunks; ++c, p += 296) {
+                uint32_t per_len[17] = {0};
+                memcpy(p, rank2sym + c * 256, 256);
+                for (int r = 0; r < 256; ++r) {
+                    const unsigned l = len_by_rank[c * 256 + r];
+                    if (l >= 1 && l <= 16) per_len[l]++;
+                }
+                for (int l = 1; l <= 16; ++l) {
+                    p[256 + 2 * (l - 1)] = (uint8_t)(per_len[l] & 0xFF);
+                    p[256 + 2 * (l - 1) + 1] = (uint8_t)(per_len[l] >> 8);
+                }
+                le32(p + 288, modes[c]);
+                le32(p + 292, entropies[c]);
+            }
+        }
+    }
+    for (uint64_t c = 0; c <= nchunks; ++c) le32(out + off[1] + 4 * c, chunk_off[c]);
+    if (off[4])
+        for (uint64_t c = 0; c < nchunks; ++c) le32(out + off[4] + 4 * c, chunk_words[c]);
+    if (off[2] && n) memcpy(out + off[2], side, (size_t)orc_side_bytes(n, layout));
+    for (uint64_t w = 0; w < payload_words; ++w) le32(out + off[3] + 4 * w, payload[w]);
+    return total;
+}

@@ -239,6 +239,19 @@ uint64_t orc_container_pack(uint8_t* out, uint64_t n, int layout, int kind, uint
                             const uint32_t* entropies, const uint32_t* chunk_off,
                             const uint8_t* side, const uint32_t* payload);
 
+/* Container, wire format version 2: version 1 plus a placement field (header byte 104: 1 slotted,
+ * 2 paged) and, for slotted streams, the words array (its offset at header byte 112, the section
+ * between the chunk offsets and the side bytes).  A paged stream has no codebook section (offset 0):
+ * its pages carry the records.  placement 0 writes the version-1 container. */
+uint64_t orc_container2_bytes(uint64_t n, int layout, int kind, int placement, uint64_t payload_words);
+uint64_t orc_container2_pack(uint8_t* out, uint64_t n, int layout, int kind, int placement,
+                             uint64_t payload_words, uint32_t mode, uint32_t entropy_q16,
+                             const uint16_t* code, const uint8_t* len, const uint8_t* rank2sym,
+                             const uint8_t* len_by_rank, const uint32_t* modes,
+                             const uint32_t* entropies, const uint32_t* chunk_off,
+                             const uint32_t* chunk_words, const uint8_t* side,
+                             const uint32_t* payload);
+
 #ifdef __cplusplus
 }
 #endif

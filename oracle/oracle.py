@@ -338,20 +338,24 @@ def container_bytes(n, layout, kind, payload_words) -> int:
 
 
 def container_pack(n, layout, payload, chunk_off, side=None, code=None, lens=None, mode=1,
-                   entropy_q16=0, rank2sym=None, len_by_rank=None, modes=None, entropies=None):
-    """The container (wire format v1) as bytes.  One codebook (code, lens, mode, entropy_q16) or
-    per-chunk canonical orders (rank2sym, len_by_rank: nchunks x 256; modes, entropies)."""
+                   entropy_q16=0, rank2sym=None, len_by_rank=None, modes=None, entropies=None,
+                   placement=0, chunk_words=None):
+    """The container as bytes.  One codebook (code, lens, mode, entropy_q16) or per-chunk canonical
+    orders (rank2sym, len_by_rank: nchunks x 256; modes, entropies).  placement 0: dense, wire
+    format version 1; 1: slotted (with chunk_words); 2: paged (no codebook section) -- version 2."""
     l = lib()
-    l.orc_container_bytes.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_uint64]
-    l.orc_container_bytes.restype = C.c_uint64
-    l.orc_container_pack.argtypes = [_u8p, C.c_uint64, C.c_int, C.c_int, C.c_uint64, C.c_uint32,
-                                     C.c_uint32, _u16p, _u8p, _u8p, _u8p, _u32p, _u32p, _u32p,
-                                     _u8p, _u32p]
-    l.orc_container_pack.restype = C.c_uint64
-    kind = 0 if rank2sym is None else 1
+    l.orc_container2_bytes.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_uint64]
+    l.orc_container2_bytes.restype = C.c_uint64
+    l.orc_container2_pack.argtypes = [_u8p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_uint64,
+                                      C.c_uint32, C.c_uint32, _u16p, _u8p, _u8p, _u8p, _u32p, _u32p,
+                                      _u32p, _u32p, _u8p, _u32p]
+    l.orc_container2_pack.restype = C.c_uint64
+    kind = 1 if (rank2sym is not None or placement == 2) else 0
     payload = _arr(payload, np.uint32)
     chunk_off = _arr(chunk_off, np.uint32)
-    total = int(l.orc_container_bytes(n, layout, kind, payload.size))
+    total = int(l.orc_container2_bytes(n, layout, kind, placement, payload.size))
+    if placement == 0:
+        assert total == container_bytes(n, layout, kind, payload.size)
     out = np.zeros(total, np.uint8)
     z8, z16, z32 = np.zeros(1, np.uint8), np.zeros(1, np.uint16), np.zeros(1, np.uint32)
     code = _arr(code, np.uint16) if code is not None else z16
@@ -361,11 +365,13 @@ def container_pack(n, layout, payload, chunk_off, side=None, code=None, lens=Non
     lbr = _arr(len_by_rank, np.uint8).reshape(-1) if len_by_rank is not None else z8
     modes = _arr(modes, np.uint32) if modes is not None else z32
     ents = _arr(entropies, np.uint32) if entropies is not None else z32
+    words = _arr(chunk_words, np.uint32) if chunk_words is not None else z32
     pay = payload if payload.size else z32
-    got = l.orc_container_pack(_p(out, _u8p), n, layout, kind, payload.size, mode, entropy_q16,
-                               _p(code, _u16p), _p(lens, _u8p), _p(r2s, _u8p), _p(lbr, _u8p),
-                               _p(modes, _u32p), _p(ents, _u32p), _p(chunk_off, _u32p),
-                               _p(side, _u8p), _p(pay, _u32p))
+    got = l.orc_container2_pack(_p(out, _u8p), n, layout, kind, placement, payload.size, mode,
+                                entropy_q16, _p(code, _u16p), _p(lens, _u8p), _p(r2s, _u8p),
+                                _p(lbr, _u8p), _p(modes, _u32p), _p(ents, _u32p),
+                                _p(chunk_off, _u32p), _p(words, _u32p), _p(side, _u8p),
+                                _p(pay, _u32p))
     assert int(got) == total
     return out
 

@@ -58,3 +58,54 @@ def test_oracle_container_fields(orc):
     out = orc.rp_decode(np.frombuffer(raw, "<u4", words, o_pay),
                         np.frombuffer(raw, "<u4", nch + 1, o_off), n, code, lens)
     assert np.array_equal(out, sym)
+
+
+def test_placed_plan_matches_oracle_sizes(lib, orc):
+    """Wire format version 2 (slotted: a words array; paged: no codebook section)."""
+    from huffman_amd import _lib as L
+    ol = orc.lib()
+    ol.orc_container2_bytes.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_uint64]
+    ol.orc_container2_bytes.restype = C.c_uint64
+    info = L.hf_container_info()
+    for n in (0, 1, 16384, 16385, 10**6 + 7):
+        for layout in (0, 1):
+            for kind, placement in ((0, 0), (1, 0), (0, 1), (1, 1), (1, 2)):
+                for words in (0, 3, 4, 12345):
+                    assert lib.hf_container_plan_placed(n, layout, kind, placement, words,
+                                                        C.byref(info)) == 0
+                    assert info.total_bytes == ol.orc_container2_bytes(n, layout, kind, placement, words)
+                    assert info.version == (1 if placement == 0 else 2)
+                    assert (info.off_chunk_words != 0) == (placement == 1)
+                    assert (info.off_codebook == 0) == (placement == 2)
+                    for off in (info.off_codebook, info.off_chunk_off, info.off_chunk_words,
+                                info.off_side, info.off_payload, info.total_bytes):
+                        assert off % 16 == 0
+    # a paged stream always has per-page records; unknown placements are refused
+    assert lib.hf_container_plan_placed(10, 0, 0, 2, 1, C.byref(info)) == L.HF_ERR_ARG
+    assert lib.hf_container_plan_placed(10, 0, 1, 3, 1, C.byref(info)) == L.HF_ERR_ARG
+
+
+def test_oracle_container_v2_fields(orc):
+    rng = np.random.default_rng(9)
+    n = 3 * 16384 + 5
+    sym = np.minimum(rng.geometric(0.2, n) - 1, 255).astype(np.uint8)
+    payload, off, code, lens = orc.rp_encode_pages(sym, 0, 1)
+    raw = orc.container_pack(n, orc.LAYOUT_U8, payload, off, placement=2).tobytes()
+    ver, hdr, layout, kind = struct.unpack_from("<4I", raw, 8)
+    assert (ver, hdr, layout, kind) == (2, 128, 0, 1)
+    n_, nch, words, o_cb, o_off, o_side, o_pay, total = struct.unpack_from("<8Q", raw, 40)
+    assert (n_, nch, words, o_cb, o_side, total) == (n, 4, payload.size, 0, 0, len(raw))
+    assert struct.unpack_from("<IIQ", raw, 104) == (2, 0, 0) and raw[120:128] == bytes(8)
+    assert np.array_equal(np.frombuffer(raw, "<u4", nch + 1, o_off), off)
+    back = orc.rp_decode_pages(np.frombuffer(raw, "<u4", words, o_pay),
+                               np.frombuffer(raw, "<u4", nch + 1, o_off), n)
+    assert np.array_equal(back, sym)
+    # slotted: the words array sits between the offsets and the payload
+    p2, slot_off, w2, c2, l2 = orc.rp_encode_blocks_slotted(sym)
+    r2s = np.zeros((nch, 256), np.uint8)
+    raw = orc.container_pack(n, orc.LAYOUT_U8, p2, slot_off, rank2sym=r2s, len_by_rank=r2s,
+                             modes=[1] * nch, entropies=[0] * nch, placement=1,
+                             chunk_words=w2).tobytes()
+    o_words = struct.unpack_from("<Q", raw, 112)[0]
+    assert struct.unpack_from("<I", raw, 104)[0] == 1 and o_words % 16 == 0
+    assert np.array_equal(np.frombuffer(raw, "<u4", nch, o_words), w2)

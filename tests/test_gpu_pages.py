@@ -242,3 +242,54 @@ def test_paged_empty_input(hf, orc):
     s = sys_.encode_blocks(t, paged=True)
     assert s.total_words == 0 and int(s.chunk_off[0].item()) == 0
     assert dec.decode(s).numel() == 0
+
+
+@pytest.mark.parametrize("kind,n", [("geom", 0), ("geom", 7), ("mixed", 9 * CH + 77), ("normal", 64 * CH)])
+def test_paged_container_round_trip(hf, orc, kind, n):
+    """Wire format version 2: header, page offsets and payload, nothing else -- the pages carry their
+    records -- byte for byte the oracle's; a stream opened from the blob decodes in place."""
+    sym = make(kind, n, 41)
+    t = to_dev(sym)
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    dec = hf.ParrallelHuffmanDecoder(ctx=sys_.ctx)
+    s = sys_.encode_blocks(t, mode=hf.HF_MODE_BEST, paged=True)
+    payload, off, _, _ = orc.rp_encode_pages(sym, 0, 3)
+    blob = s.to_container(sys_.ctx)
+    assert blob.numel() == s.container_bytes()
+    exp = orc.container_pack(n, orc.LAYOUT_U8, payload, off, placement=2)
+    assert np.array_equal(blob.cpu().numpy(), exp)
+    info = hf.L.hf_container_info()
+    assert hf.L.lib().hf_container_open(sys_.ctx.handle, C.c_void_p(blob.data_ptr()), blob.numel(),
+                                        C.byref(info)) == 0
+    assert (info.version, info.placement, info.off_codebook, info.off_chunk_words) == (2, 2, 0, 0)
+    s2 = hf.EncodedStream.from_container(blob, ctx=sys_.ctx)
+    assert s2.paged and s2.chunk_codebooks is None and s2.total_words == payload.size
+    assert torch.equal(dec.decode(s2), t)
+    if n >= 2 * CH:
+        ids = to_dev(np.array([s.nchunks - 2, 0], np.int32))
+        got = dec.decode_blocks(s2, ids).cpu().numpy()
+        assert np.array_equal(got[:CH], sym[(s.nchunks - 2) * CH:(s.nchunks - 1) * CH])
+        assert np.array_equal(got[CH:], sym[:CH])
+        # a version-2 header with a damaged placement or words offset is refused
+        for pos, val in ((104, 3), (104, 0), (112, 16), (108, 1)):
+            bad = blob.clone()
+            bad[pos] = val
+            assert hf.L.lib().hf_container_open(sys_.ctx.handle, C.c_void_p(bad.data_ptr()),
+                                                bad.numel(), C.byref(info)) == hf.L.HF_ERR_CORRUPT
+
+
+def test_paged_bf16_container(hf, orc):
+    n = 5 * CH + 100
+    rng = np.random.default_rng(5)
+    bits = ((rng.standard_normal(n) * 0.02).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+    t = to_dev(bits).view(torch.bfloat16)
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    s = sys_.encode_blocks(t, mode=hf.HF_MODE_HUFFMAN, paged=True)
+    esym, eside = orc.symbolize(bits, orc.LAYOUT_BF16_EXP)
+    payload, off, _, _ = orc.rp_encode_pages(esym, 0, 1)
+    blob = s.to_container(sys_.ctx)
+    exp = orc.container_pack(n, orc.LAYOUT_BF16_EXP, payload, off, side=eside, placement=2)
+    assert np.array_equal(blob.cpu().numpy(), exp)
+    s2 = hf.EncodedStream.from_container(blob, ctx=sys_.ctx)
+    out = hf.ParrallelHuffmanDecoder(ctx=sys_.ctx).decode(s2)
+    assert torch.equal(out.view(torch.int16), t.view(torch.int16))

@@ -60,8 +60,20 @@ def test_slotted_stream_matches_the_oracle(hf, orc, kind, n):
     for c in {0, nch // 2, nch - 1}:
         assert np.array_equal(sp[slot_off[c]: slot_off[c] + words[c]], dp[d_off[c]: d_off[c + 1]])
     assert torch.equal(dec.decode(s), t)
-    with pytest.raises(ValueError):
-        s.to_container()
+    # stored form: wire format version 2 with the words array, byte for byte the oracle's
+    blob = s.to_container(sys_.ctx)
+    r2s = np.stack([orc.aw_symbol_sort(orc.aw_symbol_stat(sym[c * 16384:(c + 1) * 16384], 256, 64))[1]
+                    for c in range(nch)]).astype(np.uint8) if nch <= 16 else None
+    if r2s is not None:
+        lbr = np.stack([lens[c][r2s[c]] for c in range(nch)])
+        ents = [orc.rp_entropy_q16_u64(orc.aw_symbol_stat(sym[c * 16384:(c + 1) * 16384], 256, 64))
+                for c in range(nch)]
+        exp = orc.container_pack(n, orc.LAYOUT_U8, payload, slot_off, rank2sym=r2s, len_by_rank=lbr,
+                                 modes=[1] * nch, entropies=ents, placement=1, chunk_words=words)
+        assert np.array_equal(blob.cpu().numpy(), exp)
+    s2 = hf.EncodedStream.from_container(blob, ctx=sys_.ctx)
+    assert s2.chunk_words is not None and s2.total_words == s.total_words
+    assert torch.equal(dec.decode(s2), t)
 
 
 def test_slotted_bf16_blocks_round_trip(hf, orc):
@@ -215,8 +227,14 @@ def test_one_codebook_slotted_stream_matches_the_oracle(hf, orc, kind, n):
     assert np.array_equal(s.chunk_words[:nch].cpu().numpy().view(np.uint32), words)
     assert np.array_equal(s.payload[: payload.size].cpu().numpy().view(np.uint32), payload)
     assert torch.equal(dec.decode(s), t)
-    with pytest.raises(ValueError):
-        s.to_container()
+    blob = s.to_container(sys_.ctx)
+    exp = orc.container_pack(n, orc.LAYOUT_U8, payload, slot_off, code=ec, lens=el, mode=1,
+                             entropy_q16=orc.rp_entropy_q16_u64(orc.aw_symbol_stat(sym, 256, 64)),
+                             placement=1, chunk_words=words)
+    assert np.array_equal(blob.cpu().numpy(), exp)
+    s2 = hf.EncodedStream.from_container(blob, ctx=sys_.ctx)
+    assert s2.chunk_words is not None and s2.codebook is not None
+    assert torch.equal(dec.decode(s2), t)
 
 
 def test_one_codebook_slotted_bf16_and_sub_fields(hf, orc):
