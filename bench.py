@@ -294,8 +294,10 @@ def main():
 
     # per-kernel device times (ms), averaged over the timed steps
     phases = ["hist", "codebook", "encode", "decode"]
-    ms = {p: sum(evs[k][i].elapsed_time(evs[k][i + 1]) for k in range(args.steps)) / args.steps
-          for i, p in enumerate(phases)}
+    per_step = {p: [evs[k][i].elapsed_time(evs[k][i + 1]) for k in range(args.steps)]
+                for i, p in enumerate(phases)}
+    ms = {p: sum(v) / len(v) for p, v in per_step.items()}
+    ms_median = {p: sorted(v)[len(v) // 2] for p, v in per_step.items()}
 
     # ---- outside the timed region: verify and measure the stream -----------------------------
     ctx.sync()
@@ -334,6 +336,7 @@ def main():
         ach = alg[p] / (ms[p] * 1e-3) / 1e9
         roof[p] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                    "frac": ach / HBM_PEAK_GBPS, "traffic": pmc.get(p), "ms": ms[p],
+                   "ms_median": ms_median[p],
                    "algorithmic_bytes": alg[p], "traffic_source": pmc_src if p in pmc else None}
     dominant = "encode" if ms["encode"] >= ms["decode"] else "decode"
 
@@ -361,6 +364,7 @@ def main():
             "decode_GBps": raw_bytes / (ms["decode"] * 1e-3) / 1e9,
             "hist_GBps": raw_bytes / (ms["hist"] * 1e-3) / 1e9,
             "codebook_ms": ms["codebook"],
+            "ms_per_phase_mean": ms, "ms_per_phase_median": ms_median,
             "compression_ratio": ratio,
             "bits_per_exponent_ideal": lbar,
             "bits_per_exponent_stream": 32.0 * total_words / n,

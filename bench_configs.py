@@ -37,6 +37,11 @@ def _phase_ms(evs, names):
     return {p: sum(e[i].elapsed_time(e[i + 1]) for e in evs) / k for i, p in enumerate(names)}
 
 
+def _phase_median(evs, names):
+    return {p: sorted(e[i].elapsed_time(e[i + 1]) for e in evs)[len(evs) // 2]
+            for i, p in enumerate(names)}
+
+
 def _roof(alg_bytes, ms, bound="hbm", **extra):
     ach = alg_bytes / (ms * 1e-3) / 1e9
     d = {"bound": bound, "achieved": ach, "peak": bench.HBM_PEAK_GBPS, "unit": "GB/s",
@@ -223,6 +228,9 @@ def make_kv_pages(torch, pages, dev, seed=7):
 
 
 def config3(args):
+    """fp8 KV pages with per-page codebooks through the paged stream (format version 2: pages with
+    their own records, sizes from the histograms, four sub-decoders per page); the dense and the
+    slotted per-block streams are timed beside it and never part of `value`."""
     import numpy as np
     import torch
     from huffman_amd import _lib as L
@@ -247,6 +255,7 @@ def config3(args):
     slots = torch.randperm(n_read, device=dev,
                            generator=torch.Generator(device=dev).manual_seed(4)).to(torch.int32)
     pool = torch.empty(n_read * CH, dtype=torch.uint8, device=dev)
+    L.check(lib.hf_ctx_reserve(h, n, L.HF_RESERVE_ALL), "reserve")
 
     def step(ev=None):
         if ev: ev[0].record()
@@ -254,16 +263,17 @@ def config3(args):
         if ev: ev[1].record()
         L.check(lib.hf_system_codebook_chunks_dev(h, P(freq), pages, 1, 0, P(cbs)), "codebooks")
         if ev: ev[2].record()
-        L.check(lib.hf_encode_chunks(h, P(t), n, 0, P(cbs), None, P(payload), payload.numel(),
-                                     P(off), None), "encode")
+        L.check(lib.hf_encode_pages(h, P(t), n, 0, P(cbs), P(freq), None, P(payload),
+                                    payload.numel(), P(off), None), "encode")
         if ev: ev[3].record()
-        L.check(lib.hf_decode_chunks(h, P(payload), payload.numel(), P(off), None, n, 0, P(cbs),
-                                     None, 0, P(out), 0), "decode")
+        L.check(lib.hf_decode_pages(h, P(payload), payload.numel(), P(off), None, n, 0, None, None,
+                                    0, P(out), 0, 0), "decode")
         if ev: ev[4].record()
-        L.check(lib.hf_decode_chunks_to(h, P(payload), payload.numel(), P(off), None, n, 0, P(cbs),
-                                        P(ids), P(slots), n_read, P(pool), n_read, 0), "read")
+        L.check(lib.hf_decode_pages(h, P(payload), payload.numel(), P(off), None, n, 0, P(ids),
+                                    P(slots), n_read, P(pool), n_read, 0), "read")
         if ev: ev[5].record()
 
+    names = ["hist", "codebook", "encode", "decode", "decode_on_read"]
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -273,29 +283,25 @@ def config3(args):
         step(evs[k])
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    ms = _phase_ms(evs, ["hist", "codebook", "encode", "decode", "decode_on_read"])
+    ms = _phase_ms(evs, names)
+    med = _phase_median(evs, names)
 
     ctx.sync()  # reports in-kernel errors of the enqueue-only calls
     total_words = int(off[pages].item()) & 0xFFFFFFFF
     ok = bool(torch.equal(out, t))
     ok = ok and bool(torch.equal(pool.view(n_read, CH)[slots.long()],
                                  t.view(pages, CH)[ids.long()]))
+    # bits of the codes alone (header word 0 of every page holds them), the stored size in full
+    o64 = off[:pages].long()
+    bits = float((payload[o64].long() >> 10).sum().item()) if pages else 0.0
+    lbar = bits / n
     lbar_stream = 32.0 * total_words / n
-    fr = freq.view(pages, 256)[:1024].cpu().numpy().astype(np.float64)
-    sample_pages = min(pages, 1024)
-    bits = 0.0
-    for c in range(0, sample_pages, 64):  # ideal bits per symbol from a sample of the records
-        _, lens, _, _ = hf.EntropyAwareHuffmanSystem(ctx=ctx).block_codebook(
-            hf.EncodedStream(n=n, layout=0, dtype=torch.uint8, payload=payload, chunk_off=off,
-                             side=None, codebook=None, chunk_codebooks=cbs), c)
-        bits += float((fr[c] * lens).sum())
-    lbar = bits / (len(range(0, sample_pages, 64)) * CH)
-    comp = 4 * total_words + 4 * (pages + 1) + L.HF_CONTAINER_CHUNK_CODEBOOK_BYTES * pages
+    comp = 4 * total_words + 4 * (pages + 1)
 
     alg = {"hist": float(n), "encode": n * (1 + lbar_stream / 8) + 4.0 * pages,
            "decode": n * (lbar_stream / 8 + 1) + 4.0 * pages,
            "decode_on_read": n_read * CH * (lbar_stream / 8 + 1)}
-    roof = {p: _roof(alg[p], ms[p]) for p in alg}
+    roof = {p: _roof(alg[p], ms[p], ms_median=med[p]) for p in alg}
     dominant = "encode" if ms["encode"] >= ms["decode"] else "decode"
     line = {
         "metric": bench.METRIC, "value": n * args.steps / elapsed / 1e9, "unit": "GB/s",
@@ -304,7 +310,8 @@ def config3(args):
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"config 3: {pages} fp8 E4M3 KV-cache pages of 16 tokens x 1024 "
                                f"bytes ({n / 1e9:.2f} GB), N(0,1) x per-channel scale, one "
-                               "EntropyAwareTreeBuilder codebook per page (Huffman forced), "
+                               "EntropyAwareTreeBuilder codebook per page (Huffman forced), paged "
+                               "stream (every page carries its record; the stored form), "
                                f"decode of all pages plus decode-on-read of {n_read} random pages "
                                "into a page pool", "pages": pages, "page_bytes": CH},
         "encode_GBps": n / ((ms["hist"] + ms["codebook"] + ms["encode"]) * 1e-3) / 1e9,
@@ -315,74 +322,102 @@ def config3(args):
         "decode_on_read_us": ms["decode_on_read"] * 1e3,
         "decode_on_read_GBps": n_read * CH / (ms["decode_on_read"] * 1e-3) / 1e9,
         "compression_ratio": n / comp, "bits_per_symbol_stream": lbar_stream,
-        "bits_per_symbol_ideal_sampled": lbar, "roundtrip_bit_exact": ok,
+        "bits_per_symbol_ideal": lbar, "roundtrip_bit_exact": ok,
+        "ms_per_phase_mean": ms, "ms_per_phase_median": med,
         "library_sha256_16": bench.library_hash(),
         "roofline": dict(roof[dominant], kernel=dominant), "roofline_all": roof,
     }
-    # The same pages in slots sized from their histograms (hf_encode_chunks_slotted): timed beside
-    # the step above, never part of `value`.
+    # one page alone: the latency floor of decode-on-read
+    one = _events(torch, 2)
+    lat = []
+    for _ in range(20):
+        one[0].record()
+        L.check(lib.hf_decode_pages(h, P(payload), payload.numel(), P(off), None, n, 0, P(ids),
+                                    P(slots), 1, P(pool), n_read, 0), "read one")
+        one[1].record()
+        torch.cuda.synchronize()
+        lat.append(one[0].elapsed_time(one[1]) * 1e3)
+    line["decode_on_read_one_page_us"] = sorted(lat)[len(lat) // 2]
+
+    # The same pages as a dense per-block stream (look-back placement, records beside the payload)
+    # and in slots sized from their histograms: timed beside the step above.
     payload_s = torch.empty(pages * L.HF_SLOT_WORDS(CH * 8), dtype=torch.int32, device=dev)
     off_s = torch.empty(pages + 4, dtype=torch.int32, device=dev)
     words_s = torch.empty(pages + 4, dtype=torch.int32, device=dev)
-    out.zero_()
-    pool.zero_()
 
-    def step_slotted(ev=None):
-        if ev: ev[0].record()
-        L.check(lib.hf_encode_chunks_slotted(h, P(t), n, 0, P(cbs), P(freq), None, P(payload_s),
-                                             payload_s.numel(), P(off_s), P(words_s), None),
-                "encode_slotted")
-        if ev: ev[1].record()
-        L.check(lib.hf_decode_chunks_slotted(h, P(payload_s), payload_s.numel(), P(off_s),
-                                             P(words_s), None, n, 0, P(cbs), None, None, 0, P(out),
-                                             0, 0), "decode_slotted")
-        if ev: ev[2].record()
-        L.check(lib.hf_decode_chunks_slotted(h, P(payload_s), payload_s.numel(), P(off_s),
-                                             P(words_s), None, n, 0, P(cbs), P(ids), P(slots),
-                                             n_read, P(pool), n_read, 0), "read_slotted")
-        if ev: ev[3].record()
+    def other(kind):
+        slotted = kind == "slotted"
 
-    for _ in range(args.warmup):
-        step_slotted()
-    torch.cuda.synchronize()
-    evs = [_events(torch, 4) for _ in range(args.steps)]
-    for k in range(args.steps):
-        step_slotted(evs[k])
-    torch.cuda.synchronize()
-    ctx.sync()
-    ms_s = _phase_ms(evs, ["encode", "decode", "decode_on_read"])
-    words_slotted = int(off_s[pages].item()) & 0xFFFFFFFF
-    ok_s = bool(torch.equal(out, t)) and bool(torch.equal(pool.view(n_read, CH)[slots.long()],
-                                                          t.view(pages, CH)[ids.long()]))
-    ok_s = ok_s and int(words_s[:pages].sum().item()) == total_words
-    ok = ok and ok_s
-    comp_s = 4 * words_slotted + 4 * (2 * pages + 1) + L.HF_CONTAINER_CHUNK_CODEBOOK_BYTES * pages
-    # (per page: 1 KiB of counts and 1 KiB of code lengths read for the slot size, two 4-byte
-    # index entries written; the payload bytes written are the slots, tails included)
-    alg_s = n + 4.0 * words_slotted + (2048.0 + 8.0) * pages
-    line["slotted"] = {
-        "encode_kernel_GBps": n / (ms_s["encode"] * 1e-3) / 1e9,
-        "encode_GBps": n / ((ms["hist"] + ms["codebook"] + ms_s["encode"]) * 1e-3) / 1e9,
-        "decode_GBps": n / (ms_s["decode"] * 1e-3) / 1e9,
-        "decode_on_read_us": ms_s["decode_on_read"] * 1e3,
-        "payload_words_over_dense": words_slotted / total_words,
-        "compression_ratio": n / comp_s, "roundtrip_bit_exact": ok_s,
-        "roofline_encode": _roof(alg_s, ms_s["encode"]),
-    }
+        def step_other(ev=None):
+            if ev: ev[0].record()
+            if slotted:
+                L.check(lib.hf_encode_chunks_slotted(h, P(t), n, 0, P(cbs), P(freq), None,
+                                                     P(payload_s), payload_s.numel(), P(off_s),
+                                                     P(words_s), None), "encode_slotted")
+            else:
+                L.check(lib.hf_encode_chunks(h, P(t), n, 0, P(cbs), None, P(payload_s),
+                                             payload_s.numel(), P(off_s), None), "encode_dense")
+            if ev: ev[1].record()
+            L.check(lib.hf_decode_chunks_slotted(h, P(payload_s), payload_s.numel(), P(off_s),
+                                                 P(words_s) if slotted else None, None, n, 0,
+                                                 P(cbs), None, None, 0, P(out), 0, 0)
+                    if slotted else
+                    lib.hf_decode_chunks(h, P(payload_s), payload_s.numel(), P(off_s), None, n, 0,
+                                         P(cbs), None, 0, P(out), 0), "decode_other")
+            if ev: ev[2].record()
+            L.check(lib.hf_decode_chunks_slotted(h, P(payload_s), payload_s.numel(), P(off_s),
+                                                 P(words_s), None, n, 0, P(cbs), P(ids), P(slots),
+                                                 n_read, P(pool), n_read, 0)
+                    if slotted else
+                    lib.hf_decode_chunks_to(h, P(payload_s), payload_s.numel(), P(off_s), None, n,
+                                            0, P(cbs), P(ids), P(slots), n_read, P(pool), n_read,
+                                            0), "read_other")
+            if ev: ev[3].record()
+
+        out.zero_()
+        pool.zero_()
+        for _ in range(args.warmup):
+            step_other()
+        torch.cuda.synchronize()
+        evs2 = [_events(torch, 4) for _ in range(args.steps)]
+        for k in range(args.steps):
+            step_other(evs2[k])
+        torch.cuda.synchronize()
+        ctx.sync()
+        m2 = _phase_ms(evs2, ["encode", "decode", "decode_on_read"])
+        w2 = int(off_s[pages].item()) & 0xFFFFFFFF
+        good = bool(torch.equal(out, t)) and bool(torch.equal(
+            pool.view(n_read, CH)[slots.long()], t.view(pages, CH)[ids.long()]))
+        stored = 4 * w2 + 4 * (pages + 1) + (4 * pages if slotted else 0) + \
+            L.HF_CONTAINER_CHUNK_CODEBOOK_BYTES * pages
+        return good, {
+            "encode_kernel_GBps": n / (m2["encode"] * 1e-3) / 1e9,
+            "decode_GBps": n / (m2["decode"] * 1e-3) / 1e9,
+            "decode_on_read_us": m2["decode_on_read"] * 1e3,
+            "payload_words_over_paged": w2 / max(1, total_words),
+            "compression_ratio": n / stored, "roundtrip_bit_exact": good,
+            "roofline_encode": _roof(n + 4.0 * w2, m2["encode"]),
+            "roofline_decode": _roof(n + 4.0 * w2, m2["decode"]),
+        }
+    for kind in ("dense", "slotted"):
+        good, line[kind] = other(kind)
+        ok = ok and good
     if not args.no_cpu_baseline:
-        m = min(pages, 49152) * CH  # 0.8 GB: about 15 s of one core
+        m = min(pages, 12288) * CH  # 0.2 GB: about 20 s of one core
         sy = t[:m].cpu().numpy()
         t0 = time.perf_counter()
-        p2, o2, c2, l2 = orc.rp_encode_blocks(sy, 0, payload_words=m // 4 + (m // CH) * 192 + 64)
+        p2, o2, c2, l2 = orc.rp_encode_pages(sy, 0, 1)
         t1 = time.perf_counter()
-        back = orc.rp_decode_blocks(p2, o2, m, c2, l2)
+        back = orc.rp_decode_pages(p2, o2, m)
         t2 = time.perf_counter()
         assert np.array_equal(back, sy)
         same = bool(np.array_equal(payload[:p2.size].cpu().numpy().view(np.uint32), p2))
+        same = same and bool(np.array_equal(off[:m // CH + 1].cpu().numpy().view(np.uint32), o2))
         line["cpu_baseline"] = {
             "value": m / (t2 - t0) / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
             "sample": f"the first {m // CH} pages of the same tensor ({m / 1e9:.2f} GB), per-page "
-                      "histogram+codebook+encode+decode, single thread, gcc -O3",
+                      "histogram+codebook+paged encode (sizing pass included)+decode, single "
+                      "thread, gcc -O3",
             "encode_GBps": m / (t1 - t0) / 1e9, "decode_GBps": m / (t2 - t1) / 1e9,
             "seconds": t2 - t0, "gpu_payload_equals_oracle_on_sample": same}
         ok = ok and same

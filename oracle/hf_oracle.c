@@ -891,24 +891,30 @@ uint64_t orc_rp_pages_bound_words(size_t n) {
     return (uint64_t)orc_num_chunks(n) * orc_rp_page_words(255, (uint64_t)ORC_CHUNK_SYMS * 16u);
 }
 
-static void set_stream_bit(uint32_t* w, uint64_t i) { w[i >> 5] |= 1u << (31u - (unsigned)(i & 31u)); }
-static unsigned get_stream_bit(const uint32_t* w, uint64_t i) {
-    return (w[i >> 5] >> (31u - (unsigned)(i & 31u))) & 1u;
+/* the low `nbits` (<= 32) bits of v, MSB first, at stream bit `at` of a zeroed area */
+static void put_bits(uint32_t* w, uint64_t at, uint32_t v, unsigned nbits) {
+    if (!nbits) return;
+    const unsigned off = (unsigned)(at & 31u);
+    const uint64_t x = (((uint64_t)v << (64 - nbits)) >> off); /* bit 63 = the word's first bit */
+    w[at >> 5] |= (uint32_t)(x >> 32);
+    if (off + nbits > 32) w[(at >> 5) + 1] |= (uint32_t)x;
 }
-
-/* bits of string (q, l) of a page of m symbols, and (bits != NULL) the bits themselves, one per byte */
-static unsigned page_string(const uint8_t* sym, size_t m, const uint16_t* code, const uint8_t* len,
-                            unsigned q, unsigned l, uint8_t* bits) {
-    unsigned t = 0;
-    for (unsigned rr = 0; rr < PAGE_SUB_ROUNDS; ++rr)
-        for (unsigned j = 0; j < ORC_GROUP; ++j) {
-            const size_t i = (((size_t)(q * PAGE_SUB_ROUNDS + rr)) * ORC_LANES + l) * ORC_GROUP + j;
-            if (i >= m) continue;
-            const unsigned L = len[sym[i]];
-            for (unsigned b = 0; b < L; ++b, ++t)
-                if (bits) bits[t] = (uint8_t)((code[sym[i]] >> (L - 1 - b)) & 1u);
-        }
-    return t;
+/* `nbits` (<= 32) stream bits from bit `at` on, first bit highest */
+static uint32_t get_bits(const uint32_t* w, uint64_t at, unsigned nbits) {
+    if (!nbits) return 0;
+    const unsigned off = (unsigned)(at & 31u);
+    uint64_t x = (uint64_t)w[at >> 5] << 32;
+    if (off + nbits > 32) x |= w[(at >> 5) + 1];
+    return (uint32_t)((x << off) >> (64 - nbits));
+}
+static uint32_t bit_reverse(uint32_t v, unsigned nbits) {
+    uint32_t r = 0;
+    for (unsigned b = 0; b < nbits; ++b) r |= ((v >> b) & 1u) << (nbits - 1 - b);
+    return r;
+}
+/* symbol index of symbol (rr, j) of string (q, l) */
+static size_t page_symbol(unsigned q, unsigned l, unsigned rr, unsigned j) {
+    return (((size_t)(q * PAGE_SUB_ROUNDS + rr)) * ORC_LANES + l) * ORC_GROUP + j;
 }
 
 /* One page from its symbols and its codebook (code / len by symbol; rank2sym / len_by_rank in
@@ -931,22 +937,36 @@ uint64_t orc_rp_encode_page(const uint8_t* sym, size_t m, const uint16_t* code, 
     for (uint32_t p = 0; p < head; ++p) out[PAGE_HDR_WORDS + p / 4] |= (uint32_t)rank2sym[p] << (8u * (p & 3u));
     uint32_t* gap = out + PAGE_HDR_WORDS + (head + 3u) / 4u;
     uint32_t* str = gap + PAGE_GAP_WORDS;
-    uint8_t* bits = (uint8_t*)malloc(64u * 16u);
     uint64_t at = 0;
     for (unsigned r = 0; r < 128; ++r) {
         const unsigned qf = r >> 6, l = r & 63u;
-        const unsigned tf = page_string(sym, m, code, len, qf, l, bits);
-        for (unsigned k = 0; k < tf; ++k)
-            if (bits[k]) set_stream_bit(str, at + k);
-        const unsigned tb = page_string(sym, m, code, len, qf + 2, l, bits);
-        const unsigned R = tf + tb;
-        for (unsigned k = 0; k < tb; ++k)
-            if (bits[k]) set_stream_bit(str, at + R - 1 - k);
+        unsigned R = 0;
+        for (unsigned dir = 0; dir < 2; ++dir)
+            for (unsigned rr = 0; rr < PAGE_SUB_ROUNDS; ++rr)
+                for (unsigned j = 0; j < ORC_GROUP; ++j) {
+                    const size_t i = page_symbol(qf + 2 * dir, l, rr, j);
+                    if (i < m) R += len[sym[i]];
+                }
+        uint64_t fwd = at, bwd = at + R; /* next free bit going up / the bit behind the next one going down */
+        for (unsigned rr = 0; rr < PAGE_SUB_ROUNDS; ++rr)
+            for (unsigned j = 0; j < ORC_GROUP; ++j) {
+                size_t i = page_symbol(qf, l, rr, j);
+                if (i < m) {
+                    const unsigned L = len[sym[i]];
+                    put_bits(str, fwd, code[sym[i]], L);
+                    fwd += L;
+                }
+                i = page_symbol(qf + 2, l, rr, j);
+                if (i < m) {
+                    const unsigned L = len[sym[i]];
+                    bwd -= L;
+                    put_bits(str, bwd, bit_reverse(code[sym[i]], L), L);
+                }
+            }
         for (unsigned b = 0; b < 12; ++b)
             if ((R >> b) & 1u) gap[(12u * r + b) >> 5] |= 1u << ((12u * r + b) & 31u);
         at += R;
     }
-    free(bits);
     return words;
 }
 
@@ -1074,14 +1094,13 @@ int orc_rp_decode_pages(const uint32_t* payload, const uint32_t* page_off, size_
                 unsigned k = 0;
                 for (unsigned rr = 0; rr < PAGE_SUB_ROUNDS && rc == 0; ++rr)
                     for (unsigned j = 0; j < ORC_GROUP; ++j) {
-                        const size_t i = (((size_t)(q * PAGE_SUB_ROUNDS + rr)) * ORC_LANES + l) * ORC_GROUP + j;
+                        const size_t i = page_symbol(q, l, rr, j);
                         if (i >= m) continue;
-                        unsigned v = 0; /* the next 16 bits of the string, zeros past the region */
-                        for (unsigned b = 0; b < 16; ++b) {
-                            unsigned bit = 0;
-                            if (k + b < R) bit = get_stream_bit(str, dir ? at + R - 1 - (k + b) : at + k + b);
-                            v = (v << 1) | bit;
-                        }
+                        /* the next 16 bits of the string, zeros past the region */
+                        const unsigned nb = R - k < 16 ? R - k : 16;
+                        unsigned v = dir ? bit_reverse(get_bits(str, at + R - k - nb, nb), nb)
+                                         : get_bits(str, at + k, nb);
+                        v <<= 16 - nb;
                         const uint16_t e = tab[v];
                         const unsigned L = e >> 8;
                         if (L == 0 || k + L > R) {
