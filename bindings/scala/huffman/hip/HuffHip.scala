@@ -33,6 +33,9 @@ trait HuffHip extends Library {
   def hf_symbol_stat(ctx: Pointer, dData: Pointer, n: Long, layout: Int, depth: Int, wtWidth: Int,
                      hFreq: Array[Long]): Int
   def hf_symbol_stat_dev(ctx: Pointer, dData: Pointer, n: Long, layout: Int, dFreq256: Pointer): Int
+  // shards on several GPUs: sum the 256 counts over the ranks of an RCCL communicator (ncclComm_t),
+  // in place, on the context's stream; every rank then builds the same codebook
+  def hf_symbol_stat_allreduce(ctx: Pointer, ncclComm: Pointer, dFreq256: Pointer): Int
   // front ends (reports/spec.md:22: FP16 / FP8 / FP4 operands, bit-plane compression): exponent
   // field -> symbol byte, the other bits -> packed side stream (Layout.FP16_EXP, FP8_E4M3_EXP,
   // FP4_E2M1_EXP), or bytes -> bit planes (Layout.BITPLANE8: no side stream, n a multiple of 8)

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("HUFFHIP_LIB") or os.path.join(_HERE, "lib", "libhuffh
 HF_ABI_VERSION = 3
 HF_OK = 0
 HF_ERR_ARG, HF_ERR_ALIGN, HF_ERR_RANGE, HF_ERR_HIP = -1, -2, -3, -4
-HF_ERR_OVERFLOW, HF_ERR_TIMEOUT, HF_ERR_CORRUPT, HF_ERR_NOMEM = -5, -6, -7, -8
+HF_ERR_OVERFLOW, HF_ERR_TIMEOUT, HF_ERR_CORRUPT, HF_ERR_NOMEM, HF_ERR_RCCL = -5, -6, -7, -8, -9
 HF_LAYOUT_U8, HF_LAYOUT_BF16_EXP, HF_LAYOUT_FP8 = 0, 1, 2
 HF_LAYOUT_FP16_EXP, HF_LAYOUT_FP8_E4M3_EXP = 3, 4
 HF_LAYOUT_FP4_E2M1_EXP, HF_LAYOUT_BITPLANE8 = 5, 6
@@ -90,6 +90,7 @@ SIGNATURES = {
     "hf_ctx_reserve": (C.c_int, [_vp, C.c_uint64, C.c_uint]),
     "hf_symbol_stat": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int, _u64p]),
     "hf_symbol_stat_dev": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, _vp]),
+    "hf_symbol_stat_allreduce": (C.c_int, [_vp, _vp, _vp]),
     "hf_fields_side_bytes": (C.c_uint64, [C.c_uint64, C.c_int]),
     "hf_fields_split": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, _vp, _vp]),
     "hf_fields_merge": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_int, _vp]),

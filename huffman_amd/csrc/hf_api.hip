@@ -1,8 +1,10 @@
 // C ABI of libhuffhip.so (declarations and reference citations: include/huffhip.h).
 // Host side only: argument checks, the per-context workspace, stream-ordered launches.
+#include <dlfcn.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <new>
 
 #include "hf_common.h"
@@ -212,6 +214,7 @@ const char* hf_error_string(int code) {
         case HF_ERR_TIMEOUT: return "in-kernel wait timed out";
         case HF_ERR_CORRUPT: return "corrupt payload or offsets";
         case HF_ERR_NOMEM: return "out of memory";
+        case HF_ERR_RCCL: return "RCCL not loadable or collective failed";
         default: return "unknown error";
     }
 }
@@ -349,6 +352,40 @@ int hf_symbol_stat_dev(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
     const hipError_t launch_err = hipGetLastError();  // before the event record can mask it
     toc(ctx);
     HF_HIP(launch_err);
+    return HF_OK;
+}
+
+// ncclAllReduce of the RCCL this process uses, looked up on first use: the library is half a
+// gigabyte and only callers that shard over GPUs need it, so libhuffhip.so does not link it.
+// (dlopen by soname returns the copy that is already loaded, whoever loaded it.)
+typedef int (*hf_nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+static hf_nccl_allreduce_fn rccl_allreduce() {
+    static std::atomic<void*> fn{nullptr};
+    void* f = fn.load(std::memory_order_acquire);
+    if (!f) {
+        const char* name = getenv("HF_RCCL_LIB");
+        void* h = dlopen(name && *name ? name : "librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return nullptr;
+        f = dlsym(h, "ncclAllReduce");
+        if (f) fn.store(f, std::memory_order_release);
+    }
+    return reinterpret_cast<hf_nccl_allreduce_fn>(f);
+}
+
+int hf_symbol_stat_allreduce(hf_ctx* ctx, void* nccl_comm, uint64_t* d_freq256) {
+    if (!ctx || !nccl_comm || !d_freq256) return HF_ERR_ARG;
+    if (!aligned16(d_freq256)) return HF_ERR_ALIGN;
+    const hf_nccl_allreduce_fn allreduce = rccl_allreduce();
+    if (!allreduce) return HF_ERR_RCCL;
+    HF_USE_DEVICE(ctx);
+    tic(ctx);
+    // ncclUint64 = 5, ncclSum = 0 (rccl.h: ncclDataType_t, ncclRedOp_t)
+    const int rc = allreduce(d_freq256, d_freq256, 256, 5, 0, nccl_comm, ctx->stream);
+    toc(ctx);
+    if (rc != 0) {
+        ctx->last_hip = rc;
+        return HF_ERR_RCCL;
+    }
     return HF_OK;
 }
 

@@ -37,6 +37,8 @@ extern "C" {
 #define HF_ERR_TIMEOUT (-6)  /* an in-kernel bounded wait ran out                          */
 #define HF_ERR_CORRUPT (-7)  /* payload / offsets inconsistent                             */
 #define HF_ERR_NOMEM (-8)
+#define HF_ERR_RCCL (-9)     /* RCCL could not be loaded, or the collective failed (the
+                                ncclResult_t is left in hf_last_hip_error)                  */
 
 /* element layouts accepted by the front ends */
 #define HF_LAYOUT_U8 0       /* symbol = byte                                              */
@@ -128,6 +130,18 @@ int hf_symbol_stat(hf_ctx* ctx, const void* d_data, uint64_t n, int layout, int 
  * ACCUMULATED into (zero it for a fresh block); no synchronisation. */
 int hf_symbol_stat_dev(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
                        uint64_t* d_freq256);
+
+/* The one exchange step of a tensor sharded over several GPUs (one context per GPU, every shard
+ * counted by hf_symbol_stat_dev on its own GPU): the 256 counts are summed over all ranks of the
+ * communicator, in place, on the context's stream -- one ncclAllReduce(sum, uint64, 256 elements,
+ * 2 KiB: latency bound, nowhere near a link's bandwidth).  Every rank then runs
+ * hf_system_codebook_dev on the same sums and gets the same tables; encode and decode stay local.
+ * The reference counts one stream in one module (symbol_stat.scala:34-38); this is that module's
+ * counter array summed across devices.  nccl_comm is an ncclComm_t of the RCCL the process uses
+ * (librccl.so.1, loaded on the first call -- libhuffhip.so itself does not link it; HF_RCCL_LIB
+ * names another file); with several communicators driven by one thread the calls go between
+ * ncclGroupStart and ncclGroupEnd as usual.  Enqueue only. */
+int hf_symbol_stat_allreduce(hf_ctx* ctx, void* nccl_comm, uint64_t* d_freq256);
 
 /* ---- sub-field front ends -------------------------------------------------------------------
  * The reference's spec lists FP16 / FP8 / FP4 operands (reports/spec.md:22) but its RTL takes 8-bit

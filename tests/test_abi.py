@@ -45,7 +45,7 @@ def test_header_constants_match_binding():
         assert m, name
         assert int(m.group(1)) == getattr(_lib, name), name
     for name in ("HF_ERR_ARG", "HF_ERR_ALIGN", "HF_ERR_RANGE", "HF_ERR_HIP", "HF_ERR_OVERFLOW",
-                 "HF_ERR_TIMEOUT", "HF_ERR_CORRUPT", "HF_ERR_NOMEM"):
+                 "HF_ERR_TIMEOUT", "HF_ERR_CORRUPT", "HF_ERR_NOMEM", "HF_ERR_RCCL"):
         m = re.search(rf"#define\s+{name}\s+\((-?\d+)\)", src)
         assert m and int(m.group(1)) == getattr(_lib, name), name
 

@@ -6,8 +6,10 @@ form one GPU allows: the RCCL all-reduce of the histogram inside a one-rank `ncc
 chain with two processes sharing the GPU and summing over gloo, one shard of the 8-way split of
 the Llama-3-70B-sized stream at full size, and `bench.py --gpus 2` started the way the driver
 starts it (the script launches its own ranks)."""
+import ctypes as C
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -103,6 +105,59 @@ def test_all_reduce_over_rccl_sums_device_counts(hf, nccl_group):
     cb = sys_.codebook(freq, hf.HF_MODE_HUFFMAN)
     s = sys_.encode_with(t, cb)
     assert torch.equal(hf.ParrallelHuffmanDecoder(ctx=sys_.ctx).decode(s), t)
+
+
+def test_c_abi_all_reduce_on_a_one_rank_communicator(hf, orc):
+    # hf_symbol_stat_allreduce through the C ABI with an ncclComm_t made by ncclCommInitAll(1):
+    # histogram kernel -> all-reduce -> codebook kernel on the context's stream, no torch
+    # collective anywhere; the tables must be the oracle's for the same counts
+    L = hf.L
+    lib = L.lib()
+    rccl = C.CDLL("librccl.so.1")
+    rccl.ncclCommInitAll.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int)]
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    comm = C.c_void_p()
+    dev0 = C.c_int(0)
+    assert rccl.ncclCommInitAll(C.byref(comm), 1, C.byref(dev0)) == 0 and comm.value
+    try:
+        ctx = hf.Context(0)
+        n = 5 * 16384 + 77
+        w = gaussian_bf16(n, seed=5)
+        t = torch.from_numpy(w.view(np.int16)).to(DEV)
+        freq = torch.zeros(256, dtype=torch.int64, device=DEV)
+        vp = lambda x: C.c_void_p(x.data_ptr())
+        assert lib.hf_symbol_stat_dev(ctx.handle, vp(t), n, L.HF_LAYOUT_BF16_EXP, vp(freq)) == 0
+        assert lib.hf_symbol_stat_allreduce(ctx.handle, comm, vp(freq)) == 0
+        cb = torch.zeros(L.HF_CODEBOOK_DEV_BYTES, dtype=torch.uint8, device=DEV)
+        assert lib.hf_system_codebook_dev(ctx.handle, vp(freq), L.HF_MODE_HUFFMAN, 0, vp(cb)) == 0
+        ctx.sync()
+        sym, _ = orc.symbolize(w, orc.LAYOUT_BF16_EXP)
+        exp = orc.aw_symbol_stat(sym, 256, 64)
+        assert np.array_equal(freq.cpu().numpy().astype(np.uint64), np.asarray(exp, np.uint64))
+        code, lens, mode, _ = hf.DeviceCodebook(ctx, cb).download()
+        ec, el = orc.rp_system_codebook(exp, 64, 0, 16)
+        assert mode == 1 and np.array_equal(code, ec) and np.array_equal(lens, el)
+        # argument checks come before anything touches RCCL
+        assert lib.hf_symbol_stat_allreduce(ctx.handle, None, vp(freq)) == L.HF_ERR_ARG
+        assert lib.hf_symbol_stat_allreduce(ctx.handle, comm, None) == L.HF_ERR_ARG
+    finally:
+        torch.cuda.synchronize()
+        rccl.ncclCommDestroy(comm)
+
+
+def test_plain_c_shard_driver_on_one_gpu():
+    # the single-process driver (ncclCommInitAll, one context per GPU, plain C over the C ABI)
+    # with the one GPU a test box has: shard = whole tensor, all-reduce over one rank
+    exe = os.path.join(ROOT, "huffman_amd", "lib", "hf_shard_driver")
+    assert os.path.exists(exe), "build it with make -C huffman_amd/csrc"
+    n = 40 * 16384 + 123
+    r = subprocess.run([exe, "--gpus", "1", "--elems", str(n)], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"rank 0: elements \[0, (\d+)\) local_count_sum (\d+) global_count_sum (\d+) "
+                  r"codebook_hash ([0-9a-f]{16}) mode 1 .* round_trip ok", r.stdout)
+    assert m and [int(m.group(i)) for i in (1, 2, 3)] == [n, n, n], r.stdout
+    assert "same_codebook_everywhere yes all_ok yes" in r.stdout
 
 
 def test_config4_shard_full_size_properties(hf):
