@@ -25,6 +25,8 @@ trait HuffHip extends Library {
   // make the context's lazily sized workspaces now (Reserve.ENCODE | CODEBOOKS | PLACED), for
   // streams of up to maxN elements: later enqueue-only calls allocate and synchronise nothing
   def hf_ctx_reserve(ctx: Pointer, maxN: Long, flags: Int): Int
+  // capturable clear (a kernel, not a memset node) for the counters the stat calls add into
+  def hf_zero_dev(ctx: Pointer, dPtr: Pointer, nwords: Long): Int
   def hf_num_chunks(n: Long): Long
   def hf_payload_bound_words(n: Long): Long                         // worst case over all codebooks
   def hf_set_timing(ctx: Pointer, enabled: Int): Int

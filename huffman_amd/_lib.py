@@ -28,6 +28,7 @@ HF_MODE_BYPASS, HF_MODE_HUFFMAN, HF_MODE_AUTO, HF_MODE_BEST = 0, 1, 2, 3
 HF_CODEBOOK_DEV_BYTES = 36864
 HF_CHUNK_CODEBOOK_BYTES = 1552
 HF_STATIC_CB_MAX_CHUNKS = 4096
+HF_STATIC_CB_SLOTS = 4
 HF_CONTAINER_VERSION = 2
 HF_CONTAINER_HEADER_BYTES = 128
 HF_CONTAINER_CHUNK_CODEBOOK_BYTES = 296
@@ -91,6 +92,7 @@ SIGNATURES = {
     "hf_symbol_stat": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int, _u64p]),
     "hf_symbol_stat_dev": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, _vp]),
     "hf_symbol_stat_allreduce": (C.c_int, [_vp, _vp, _vp]),
+    "hf_zero_dev": (C.c_int, [_vp, _vp, C.c_uint64]),
     "hf_fields_side_bytes": (C.c_uint64, [C.c_uint64, C.c_int]),
     "hf_fields_split": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, _vp, _vp]),
     "hf_fields_merge": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_int, _vp]),

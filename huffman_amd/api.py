@@ -9,6 +9,7 @@ through the HIP library or raises.
 from __future__ import annotations
 
 import ctypes as C
+import functools
 from dataclasses import dataclass
 from typing import Optional
 
@@ -106,6 +107,11 @@ class Context:
     def sync(self) -> None:
         check(L.lib().hf_sync(self._h), "hf_sync")
 
+    def reserve(self, max_n: int, flags: int = L.HF_RESERVE_ALL) -> None:
+        """Make the context's workspaces now, for streams of up to max_n elements: afterwards no
+        enqueue-only call with n <= max_n allocates, frees or synchronises (hf_ctx_reserve)."""
+        check(L.lib().hf_ctx_reserve(self._h, int(max_n), int(flags)), "hf_ctx_reserve")
+
     def set_timing(self, on: bool) -> None:
         check(L.lib().hf_set_timing(self._h, 1 if on else 0), "hf_set_timing")
 
@@ -153,6 +159,18 @@ class _Module:
 
 
 # ---------------------------------------------------------------------------------------------
+def _on_ctx_stream(method):
+    """Run a method with the context's stream as torch's current stream, so that every tensor it
+    allocates belongs to the stream the kernels write it on: the caching allocator then cannot hand
+    a dropped temporary (or a result not yet consumed) to other current-stream work while a kernel
+    enqueued on the context's stream still uses it."""
+    @functools.wraps(method)
+    def run(self, *a, **k):
+        with torch.cuda.stream(self.ctx.stream):
+            return method(self, *a, **k)
+    return run
+
+
 class SymbolStat(_Module):
     """symbol_stat.scala:6-58.  ``freq_out`` of one block of symbols."""
 
@@ -531,6 +549,7 @@ class EntropyAwareHuffmanSystem(_Module):
               "hf_system_codebook_dev")
         return cb
 
+    @_on_ctx_stream
     def codebook_of_block(self, data_in: torch.Tensor, mode: int = HF_MODE_AUTO,
                           min_freq_threshold: int = 0, layout: Optional[int] = None,
                           freq256: Optional[torch.Tensor] = None,
@@ -548,6 +567,7 @@ class EntropyAwareHuffmanSystem(_Module):
             "hf_system_codebook_block_dev")
         return cb, freq256
 
+    @_on_ctx_stream
     def encode_with(self, data_in: torch.Tensor, cb: DeviceCodebook, layout: Optional[int] = None,
                     payload: Optional[torch.Tensor] = None, side: Optional[torch.Tensor] = None,
                     chunk_off: Optional[torch.Tensor] = None, sync: bool = True) -> EncodedStream:
@@ -626,6 +646,7 @@ class EntropyAwareHuffmanSystem(_Module):
         cb = self.codebook(freq, mode, min_freq_threshold)
         return self.encode_with(data_in, cb, layout)
 
+    @_on_ctx_stream
     def _encode_slotted(self, data_in, mode, layout, min_freq_threshold) -> EncodedStream:
         lay = layout_of(data_in) if layout is None else layout
         n, dev, h = data_in.numel(), data_in.device, self.ctx.handle
@@ -668,6 +689,7 @@ class EntropyAwareHuffmanSystem(_Module):
                              chunk_words=chunk_words)
 
     # -- per-block codebooks (one codebook per 16384-symbol chunk, e.g. a KV-cache page) --------
+    @_on_ctx_stream
     def encode_blocks(self, data_in: torch.Tensor, mode: int = HF_MODE_AUTO,
                       layout: Optional[int] = None, min_freq_threshold: int = 0,
                       sync: bool = True, slotted: bool = False,
@@ -786,6 +808,7 @@ class EntropyAwareHuffmanSystem(_Module):
               "hf_chunk_codebook_download")
         return code, lens, int(mode.value), int(ent.value)
 
+    @_on_ctx_stream
     def encode_pairs(self, data_in: torch.Tensor, cb: DeviceCodebook,
                      layout: Optional[int] = None) -> np.ndarray:
         """``encoded_out`` beats, one per symbol: columns code, length, compression_mode."""
@@ -810,6 +833,7 @@ class ParrallelHuffmanDecoder(_Module):  # spelling as in decoder/top_decoder.sc
         if depth != 256 or symWidth != 8 or maxCodeLen != 16:
             raise ValueError("the packed stream is defined for symWidth=8, depth=256, maxCodeLen=16")
 
+    @_on_ctx_stream
     def _merge_fields(self, s: EncodedStream, sym: torch.Tensor,
                       out: Optional[torch.Tensor]) -> torch.Tensor:
         """``hf_fields_merge``: decoded symbol bytes + the stream's side fields -> elements."""
@@ -827,6 +851,7 @@ class ParrallelHuffmanDecoder(_Module):  # spelling as in decoder/top_decoder.sc
         import dataclasses
         return dataclasses.replace(s, layout=HF_LAYOUT_U8, dtype=torch.uint8, side=None)
 
+    @_on_ctx_stream
     def decode_blocks(self, s: EncodedStream, chunk_ids: Optional[torch.Tensor] = None,
                       out: Optional[torch.Tensor] = None, check_stream: bool = True) -> torch.Tensor:
         """Decode a stream with per-block codebooks.  With ``chunk_ids`` (int32 device tensor)
@@ -871,6 +896,7 @@ class ParrallelHuffmanDecoder(_Module):  # spelling as in decoder/top_decoder.sc
               "hf_decode_chunks")
         return out[:n_out]
 
+    @_on_ctx_stream
     def decode_blocks_to(self, s: EncodedStream, chunk_ids: torch.Tensor, out_slots: torch.Tensor,
                          page_pool: torch.Tensor, check_stream: bool = True) -> torch.Tensor:
         """Decode-on-read into a paged buffer: chunk ``chunk_ids[k]`` lands in page
@@ -910,6 +936,7 @@ class ParrallelHuffmanDecoder(_Module):  # spelling as in decoder/top_decoder.sc
                                           1 if check_stream else 0), "hf_decode_chunks_to")
         return page_pool
 
+    @_on_ctx_stream
     def decode(self, s: EncodedStream, out: Optional[torch.Tensor] = None,
                check_stream: bool = True) -> torch.Tensor:
         if s.chunk_codebooks is not None or s.paged:

@@ -28,17 +28,23 @@ struct hf_ctx {
     unsigned long long* d_scan_aux;  // group totals of the slot-offset scan, allocated on first use
     size_t scan_aux_bytes;
     void* d_static_cbscratch;  // this device's copy of `scratch` below (never freed)
+    int static_slot;           // slice of it this context holds, -1 before its first static call
     hipEvent_t ev0, ev1;
     int timing;
     int timed;
     int last_hip;
 };
 
-// Scratch block of hf_system_codebook_chunks_static, the entry point that allocates nothing: room
-// for HF_STATIC_CB_MAX_CHUNKS per-block codebooks in flight between the three codebook kernels.
-// Every GPU the library runs on holds its own copy until the process ends; host code never uses
-// the array's name as an address, only the pointer hipGetSymbolAddress returned for the device.
-static __device__ __align__(256) unsigned char scratch[HF_STATIC_CB_MAX_CHUNKS * 1040u];
+// Scratch of hf_system_codebook_chunks_static, the entry point that allocates nothing:
+// HF_STATIC_CB_SLOTS slices, each with room for HF_STATIC_CB_MAX_CHUNKS per-block codebooks in
+// flight between the three codebook kernels.  Every GPU the library runs on holds its own copy
+// until the process ends; host code never uses the array's name as an address, only the pointer
+// hipGetSymbolAddress returned for the device.
+static constexpr size_t kStaticSliceBytes = (size_t)HF_STATIC_CB_MAX_CHUNKS * HF_CB_SCRATCH_PER_CHUNK;
+static __device__ __align__(256) unsigned char scratch[HF_STATIC_CB_SLOTS * kStaticSliceBytes];
+// which slices of each GPU's copy are held by a live context (bit i = slice i)
+static constexpr int kMaxDevices = 64;
+static std::atomic<unsigned> g_static_slices[kMaxDevices];
 
 namespace {
 
@@ -228,6 +234,7 @@ int hf_ctx_create(hf_ctx** out, int device, void* stream) {
     if (!ctx) return HF_ERR_NOMEM;
     memset(ctx, 0, sizeof(*ctx));
     ctx->device = device;
+    ctx->static_slot = -1;
     ctx->stream = reinterpret_cast<hipStream_t>(stream);
     int prev_dev = -1;
     (void)hipGetDevice(&prev_dev);
@@ -280,6 +287,8 @@ int hf_ctx_destroy(hf_ctx* ctx) {
     if (ctx->d_scan_aux) (void)hipFree(ctx->d_scan_aux);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->static_slot >= 0)
+        g_static_slices[ctx->device].fetch_and(~(1u << ctx->static_slot), std::memory_order_acq_rel);
     if (prev_dev >= 0 && prev_dev != ctx->device) (void)hipSetDevice(prev_dev);
     delete ctx;
     return HF_OK;
@@ -318,6 +327,16 @@ int hf_ctx_reserve(hf_ctx* ctx, uint64_t max_n, unsigned flags) {
         if (int rc = ensure_cbscratch(ctx)) return rc;
     if (flags & HF_RESERVE_PLACED)
         if (int rc = ensure_scan_aux(ctx, nchunks)) return rc;
+    return HF_OK;
+}
+
+int hf_zero_dev(hf_ctx* ctx, void* d_ptr, uint64_t nwords) {
+    if (!ctx || (nwords && !d_ptr)) return HF_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(d_ptr) & 3u) return HF_ERR_ALIGN;
+    if (nwords > (1ull << 40)) return HF_ERR_RANGE;
+    HF_USE_DEVICE(ctx);
+    zero_words(static_cast<uint32_t*>(d_ptr), nwords, ctx->stream);
+    HF_HIP(hipGetLastError());
     return HF_OK;
 }
 
@@ -762,8 +781,29 @@ int hf_system_codebook_chunks_dev(hf_ctx* ctx, const uint32_t* d_freq_chunks, ui
 // The same kernels with the batch scratch in the static device array: nothing is allocated or
 // freed on this path (hf_ctx_create fetched the array's address for the context's device).  The
 // kernels overwrite every scratch word they later read, so nothing has to be cleared between
-// calls; two calls in flight on one GPU at the same time (two contexts, two streams) would share
-// the block and race.
+// calls.  A context works in a slice of its own, claimed here on its first call and released by
+// hf_ctx_destroy (which drains the stream first): calls of one context are ordered by its stream,
+// calls of different contexts never touch the same bytes.
+static int claim_static_slice(hf_ctx* ctx) {
+    if (ctx->static_slot >= 0) return HF_OK;
+    if (ctx->device >= kMaxDevices) return HF_ERR_NOMEM;
+    std::atomic<unsigned>& held = g_static_slices[ctx->device];
+    unsigned cur = held.load(std::memory_order_acquire);
+    for (;;) {
+        int slot = -1;
+        for (unsigned i = 0; i < HF_STATIC_CB_SLOTS; ++i)
+            if (!(cur >> i & 1u)) {
+                slot = (int)i;
+                break;
+            }
+        if (slot < 0) return HF_ERR_NOMEM;  // every slice of this GPU is held by a live context
+        if (held.compare_exchange_weak(cur, cur | (1u << slot), std::memory_order_acq_rel)) {
+            ctx->static_slot = slot;
+            return HF_OK;
+        }
+    }
+}
+
 int hf_system_codebook_chunks_static(hf_ctx* ctx, const uint32_t* d_freq_chunks, uint64_t nchunks,
                                      int mode, uint64_t min_freq_threshold,
                                      void* d_chunk_codebooks) {
@@ -774,11 +814,15 @@ int hf_system_codebook_chunks_static(hf_ctx* ctx, const uint32_t* d_freq_chunks,
     if (!aligned16(d_freq_chunks) || !aligned16(d_chunk_codebooks)) return HF_ERR_ALIGN;
     if (nchunks > HF_STATIC_CB_MAX_CHUNKS) return HF_ERR_RANGE;  // more than the block holds
     if (!ctx->d_static_cbscratch) return HF_ERR_HIP;
+    if (nchunks == 0) return HF_OK;
+    if (int rc = claim_static_slice(ctx)) return rc;
     HF_USE_DEVICE(ctx);
     tic(ctx);
     hf_launch_system_chunks(d_freq_chunks, nchunks, mode, min_freq_threshold,
                             reinterpret_cast<hf_chunk_cb*>(d_chunk_codebooks),
-                            ctx->d_static_cbscratch, HF_STATIC_CB_MAX_CHUNKS, ctx->stream);
+                            static_cast<unsigned char*>(ctx->d_static_cbscratch) +
+                                (size_t)ctx->static_slot * kStaticSliceBytes,
+                            HF_STATIC_CB_MAX_CHUNKS, ctx->stream);
     const hipError_t launch_err = hipGetLastError();
     toc(ctx);
     HF_HIP(launch_err);

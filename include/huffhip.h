@@ -119,6 +119,15 @@ int hf_last_hip_error(hf_ctx* ctx);
 #define HF_RESERVE_PLACED 4u
 #define HF_RESERVE_ALL 7u
 int hf_ctx_reserve(hf_ctx* ctx, uint64_t max_n, unsigned flags);
+/* Clear nwords 32-bit words at d_ptr (4-byte aligned) on the context's stream with a kernel: the
+ * clear to use in front of the accumulating calls (hf_symbol_stat_dev, hf_symbol_stat_fold_dev)
+ * in a sequence that is captured into a HIP graph.  Small hipMemsetAsync nodes captured inside
+ * this library's pipelines were seen to replay with another node's fill pattern on ROCm 7.2; the
+ * minimal program tools/memset_graph_repro.hip (two memset nodes and a kernel) replays correctly
+ * there, so the cause is not pinned down, and a kernel node avoids the question.  No counterpart
+ * in the reference (its counters are cleared by the flush port, symbol_stat.scala:41-46).
+ * Enqueue only. */
+int hf_zero_dev(hf_ctx* ctx, void* d_ptr, uint64_t nwords);
 
 /* ---- SymbolStat (symbol_stat.scala:6-58) -------------------------------------------------- */
 /* start + stream of n beats + done: histogram of one block.  freq[s mod N] counts; the
@@ -286,12 +295,16 @@ int hf_system_codebook_chunks_dev(hf_ctx* ctx, const uint32_t* d_freq_chunks, ui
 /* hf_system_codebook_chunks_dev for callers that cannot allocate: code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.
  * The scratch the three codebook kernels pass a batch through sits in a static device array of
- * HF_STATIC_CB_MAX_CHUNKS x 1040 bytes (4.06 MiB, held by every GPU the library runs on until the
- * process ends) whose address hf_ctx_create looked up for the context's device, so the call
- * allocates and frees nothing; same arguments, same records, bit for bit.  nchunks above
- * HF_STATIC_CB_MAX_CHUNKS is refused with HF_ERR_RANGE.  All calls on one GPU share the block:
- * two of them in flight at the same time (different contexts or streams) race. */
+ * HF_STATIC_CB_SLOTS slices of HF_STATIC_CB_MAX_CHUNKS x 1040 bytes (16.25 MiB in all, held by
+ * every GPU the library runs on until the process ends), so the call allocates and frees nothing;
+ * same arguments, same records, bit for bit.  nchunks above HF_STATIC_CB_MAX_CHUNKS is refused
+ * with HF_ERR_RANGE.  A context takes one slice of its GPU's array at its first call here (host
+ * bookkeeping only) and gives it back in hf_ctx_destroy, so contexts on different streams of one
+ * GPU never share scratch and calls of one context are ordered by its stream; the call of a
+ * context that finds all HF_STATIC_CB_SLOTS slices of its GPU taken returns HF_ERR_NOMEM and
+ * launches nothing. */
 #define HF_STATIC_CB_MAX_CHUNKS 4096u
+#define HF_STATIC_CB_SLOTS 4u
 int hf_system_codebook_chunks_static(hf_ctx* ctx, const uint32_t* d_freq_chunks, uint64_t nchunks,
                                      int mode, uint64_t min_freq_threshold,
                                      void* d_chunk_codebooks);

@@ -100,3 +100,52 @@ def test_per_block_pipeline_replays_from_a_captured_graph(hf, orc, slotted):
         total = int(s.chunk_off[pages].item())
         assert total == payload.size
         assert np.array_equal(s.payload[:total].cpu().numpy().view(np.uint32), payload)
+
+
+def test_reserved_context_captures_calls_it_never_ran(hf):
+    # a context whose only earlier call was a histogram of a tiny tensor: hf_ctx_reserve sizes every
+    # workspace for 70 000 blocks (more than the descriptor array's first size), after which the
+    # packed, the per-block (dense and slotted) and the paged pipelines are captured cold
+    pages = 70_000
+    n = pages * 16384
+    side = torch.cuda.Stream()
+    ctx = hf.Context(0, stream=side)
+    system, decoder, stat = (hf.EntropyAwareHuffmanSystem(ctx=ctx),
+                             hf.ParrallelHuffmanDecoder(ctx=ctx), hf.SymbolStat(ctx=ctx))
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    t = (torch.randn(n, device=DEV, generator=gen) * 9).abs().to(torch.uint8)
+    freq = torch.zeros(256, dtype=torch.int64, device=DEV)
+    with torch.cuda.stream(side):
+        stat.accumulate(t[:1000].contiguous(), freq)      # the warm-up: another call, a smaller n
+    ctx.reserve(n)
+    side.synchronize()
+    outs = [torch.empty(n, dtype=torch.uint8, device=DEV) for _ in range(4)]
+    cb = hf.DeviceCodebook(ctx)
+    keep = []
+
+    def block():
+        freq.zero_()
+        stat.accumulate(t, freq)
+        system.codebook(freq, hf.HF_MODE_HUFFMAN, out=cb)
+        s = system.encode_with(t, cb, sync=False)
+        decoder.decode(s, out=outs[0], check_stream=False)
+        keep.append(s)
+        for k, kw in enumerate(({}, {"slotted": True}, {"paged": True})):
+            s = system.encode_blocks(t, mode=hf.HF_MODE_HUFFMAN, sync=False, **kw)
+            decoder.decode_blocks(s, out=outs[1 + k], check_stream=False)
+            keep.append(s)
+
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        block()
+    for seed in (2, 3):
+        gen.manual_seed(seed)
+        t.copy_((torch.randn(n, device=DEV, generator=gen) * (3 * seed)).abs().to(torch.uint8))
+        for o in outs:
+            o.zero_()
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        ctx.sync()
+        for o in outs:
+            assert torch.equal(o, t)

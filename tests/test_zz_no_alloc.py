@@ -110,3 +110,98 @@ def test_records_from_the_static_path_encode_and_decode(hf, orc):
     f7 = orc.aw_symbol_stat(sym[7 * 16384:8 * 16384], 256, 64)
     ec, el = orc.rp_system_codebook(f7, 64, 0, 16)
     assert mode == 1 and np.array_equal(code, ec) and np.array_equal(lens, el)
+
+
+def _static_call(hf, ctx, freq_t, nchunks, cbs, mode=None):
+    return hf.L.lib().hf_system_codebook_chunks_static(
+        ctx.handle, C.c_void_p(freq_t.data_ptr()), nchunks,
+        hf.HF_MODE_HUFFMAN if mode is None else mode, 0, C.c_void_p(cbs.data_ptr()))
+
+
+def test_static_entry_point_allocates_nothing(hf):
+    # the property the entry point exists for: (a) free device memory does not move across the
+    # first call of a fresh context, (b) that first call goes through inside a stream capture,
+    # where any hipMalloc, hipFree or synchronisation fails the call and the capture
+    L = hf.L
+    rng = np.random.default_rng(11)
+    pages = 700
+    freq = torch.from_numpy(_counts(rng, pages, "mixed")).to(DEV).contiguous()
+    exp = _records(hf, L.lib().hf_system_codebook_chunks_dev, hf.Context(0), freq, pages,
+                   hf.HF_MODE_HUFFMAN, 0)
+    cbs = torch.full_like(exp, 0xA5)       # (record bytes no kernel writes keep the fill)
+    ctx = hf.Context(0)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    assert _static_call(hf, ctx, freq, pages, cbs) == 0
+    ctx.sync()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 == free0
+    assert torch.equal(cbs, exp)
+    ctx.close()
+
+    side = torch.cuda.Stream()
+    fresh = hf.Context(0, stream=side)   # no call of any kind before the capture
+    cbs2 = torch.full_like(exp, 0xA5)
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        rc = _static_call(hf, fresh, freq, pages, cbs2)
+    assert rc == 0
+    assert not torch.equal(cbs2, exp)    # captured, not run
+    for seed in (1, 2):
+        nxt = torch.from_numpy(_counts(np.random.default_rng(seed), pages, "mixed")).to(DEV)
+        freq.copy_(nxt)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        want = _records(hf, L.lib().hf_system_codebook_chunks_dev, hf.Context(0), freq, pages,
+                        hf.HF_MODE_HUFFMAN, 0)
+        assert torch.equal(cbs2, want)
+    fresh.close()
+
+
+def test_static_scratch_is_private_to_a_context(hf):
+    # two contexts on two streams of one GPU, full-size calls enqueued back to back without any
+    # synchronisation between them: each works in its own slice of the static array, so both get
+    # the records of the allocating entry point
+    L = hf.L
+    lib = L.lib()
+    rng = np.random.default_rng(99)
+    pages = L.HF_STATIC_CB_MAX_CHUNKS
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    ctxs = [hf.Context(0, stream=s) for s in streams]
+    freqs = [torch.from_numpy(_counts(rng, 64, "mixed")).to(DEV).repeat(pages // 64, 1).contiguous()
+             for _ in range(2)]
+    exps = [_records(hf, lib.hf_system_codebook_chunks_dev, hf.Context(0), f, pages,
+                     hf.HF_MODE_BEST, 0) for f in freqs]
+    outs = [[torch.full_like(exps[0], 0xA5) for _ in range(6)] for _ in range(2)]
+    torch.cuda.synchronize()
+    for it in range(6):
+        for k in (0, 1):
+            assert _static_call(hf, ctxs[k], freqs[k], pages, outs[k][it], hf.HF_MODE_BEST) == 0
+    torch.cuda.synchronize()
+    for k in (0, 1):
+        ctxs[k].sync()
+        for it in range(6):
+            assert torch.equal(outs[k][it], exps[k]), (k, it)
+    # the slices are a fixed pool: contexts past HF_STATIC_CB_SLOTS on one GPU are refused, with
+    # nothing launched, until a holder is destroyed
+    one = freqs[0][:256].contiguous()
+    cbs = torch.full((L.HF_CHUNK_CODEBOOK_BYTES,), 0xA5, dtype=torch.uint8, device=DEV)
+    extra, refused = [], None
+    for _ in range(L.HF_STATIC_CB_SLOTS + 1):
+        c = hf.Context(0)
+        rc = _static_call(hf, c, one, 1, cbs)
+        if rc == L.HF_ERR_NOMEM:
+            refused = c
+            break
+        assert rc == 0
+        extra.append(c)
+    assert refused is not None and len(extra) <= L.HF_STATIC_CB_SLOTS - 2
+    torch.cuda.synchronize()
+    ctxs[0].close()
+    assert _static_call(hf, refused, one, 1, cbs) == 0
+    refused.sync()
+    assert torch.equal(cbs, exps[0][: L.HF_CHUNK_CODEBOOK_BYTES])
+    for c in extra + [refused, ctxs[1]]:
+        c.close()
