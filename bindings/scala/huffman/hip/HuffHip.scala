@@ -133,6 +133,15 @@ trait HuffHip extends Library {
   def hf_decode_pages(ctx: Pointer, dPayload: Pointer, payloadWords: Long, dPageOff: Pointer,
                       dSide: Pointer, n: Long, layout: Int, dPageIds: Pointer, dOutSlots: Pointer,
                       nIds: Long, dOut: Pointer, nSlots: Long, check: Int): Int
+  // the same pages without records, all coded with the stream's one codebook
+  def hf_encode_pages_shared(ctx: Pointer, dData: Pointer, n: Long, layout: Int, dCodebook: Pointer,
+                             dFreqChunks: Pointer, dSide: Pointer, dPayload: Pointer,
+                             payloadCapWords: Long, dPageOff: Pointer,
+                             hTotalWords: LongByReference): Int
+  def hf_decode_pages_shared(ctx: Pointer, dPayload: Pointer, payloadWords: Long, dPageOff: Pointer,
+                             dSide: Pointer, n: Long, layout: Int, dCodebook: Pointer,
+                             dPageIds: Pointer, dOutSlots: Pointer, nIds: Long, dOut: Pointer,
+                             nSlots: Long, check: Int): Int
   def hf_page_codebook_download(ctx: Pointer, dPayload: Pointer, payloadWords: Long,
                                 dPageOff: Pointer, page: Long, hCode: Array[Short],
                                 hLen: Array[Byte], mode: IntByReference,

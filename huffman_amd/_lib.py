@@ -137,6 +137,10 @@ SIGNATURES = {
                                   _u64p]),
     "hf_decode_pages": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, C.c_uint64, C.c_int, _vp, _vp,
                                   C.c_uint64, _vp, C.c_uint64, C.c_int]),
+    "hf_encode_pages_shared": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, _vp, _vp, _vp, _vp, C.c_uint64,
+                                         _vp, _u64p]),
+    "hf_decode_pages_shared": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, C.c_uint64, C.c_int, _vp, _vp,
+                                         _vp, C.c_uint64, _vp, C.c_uint64, C.c_int]),
     "hf_page_codebook_download": (C.c_int, [_vp, _vp, C.c_uint64, _vp, C.c_uint64, _u16p, _u8p, _ip,
                                             _u32p]),
     "hf_chunk_codebook_download": (C.c_int, [_vp, _vp, C.c_uint64, _u16p, _u8p, _ip, _u32p]),

@@ -407,8 +407,10 @@ class EncodedStream:
     # a slotted stream (hf_encode_chunks_slotted): chunk_off are slot starts, and these the words
     # each chunk filled of its slot; None for a dense (format-v1) payload
     chunk_words: Optional[torch.Tensor] = None
-    # a paged stream (hf_encode_pages, format version 2): chunk_off are page offsets, every page
-    # carries its own codebook record, and the decoder needs nothing but payload and offsets
+    # a paged stream (format version 2): chunk_off are page offsets.  With codebook = None
+    # (hf_encode_pages) every page carries its own codebook record and the decoder needs nothing
+    # but payload and offsets; with a codebook (hf_encode_pages_shared) the pages have no record
+    # and are all coded with that one table
     paged: bool = False
 
     @property
@@ -422,8 +424,9 @@ class EncodedStream:
         counts, mode, entropy).  Section padding and the header are left to container_bytes()."""
         assert self.total_words is not None
         side = side_bytes(self.n, self.layout)
-        if self.paged:  # the records are part of the pages
-            return 4 * self.total_words + side + 4 * (self.nchunks + 1)
+        if self.paged:  # the records are part of the pages, unless one table codes them all
+            return 4 * self.total_words + side + 4 * (self.nchunks + 1) + \
+                (256 * 3 if self.codebook is not None else 0)
         books = 256 * 3 if self.chunk_codebooks is None \
             else L.HF_CONTAINER_CHUNK_CODEBOOK_BYTES * self.nchunks
         index = 4 * (self.nchunks + 1) + (4 * self.nchunks if self.chunk_words is not None else 0)
@@ -441,7 +444,7 @@ class EncodedStream:
     def _plan(self):
         assert self.total_words is not None, "encode with sync=True first"
         info = L.hf_container_info()
-        per_chunk = self.chunk_codebooks is not None or self.paged
+        per_chunk = self.chunk_codebooks is not None or (self.paged and self.codebook is None)
         check(L.lib().hf_container_plan_placed(self.n, self.layout, 1 if per_chunk else 0,
                                                self.placement, self.total_words, C.byref(info)),
               "hf_container_plan_placed")
@@ -458,7 +461,7 @@ class EncodedStream:
         ctx = ctx if ctx is not None else default_context()
         info, per_chunk = self._plan()
         blob = torch.empty(int(info.total_bytes), dtype=torch.uint8, device=self.payload.device)
-        if self.paged:
+        if self.paged and per_chunk:
             cb_ptr = 0
         else:
             cb_ptr = self.chunk_codebooks.data_ptr() if per_chunk else self.codebook.ptr
@@ -486,7 +489,7 @@ class EncodedStream:
         paged = info.placement == L.HF_PLACEMENT_PAGED
         per_chunk = info.codebook_kind == L.HF_CODEBOOK_PER_CHUNK
         cbs, cb, cb_ptr = None, None, 0
-        if paged:
+        if paged and per_chunk:
             pass
         elif per_chunk:
             cbs = torch.empty(max(1, nch) * L.HF_CHUNK_CODEBOOK_BYTES, dtype=torch.uint8,
@@ -570,12 +573,24 @@ class EntropyAwareHuffmanSystem(_Module):
     @_on_ctx_stream
     def encode_with(self, data_in: torch.Tensor, cb: DeviceCodebook, layout: Optional[int] = None,
                     payload: Optional[torch.Tensor] = None, side: Optional[torch.Tensor] = None,
-                    chunk_off: Optional[torch.Tensor] = None, sync: bool = True) -> EncodedStream:
+                    chunk_off: Optional[torch.Tensor] = None, sync: bool = True,
+                    paged: bool = False) -> EncodedStream:
+        """Pack ``data_in`` with a codebook made elsewhere (another tensor's, a global one summed
+        over ranks).  ``paged``: as pages without records (``hf_encode_pages_shared``), sized from
+        per-page counts taken here."""
         lay = layout_of(data_in) if layout is None else layout
         data_in = data_in.contiguous()
         n = data_in.numel()
         dev = data_in.device
         nch = (n + HF_CHUNK_SYMS - 1) // HF_CHUNK_SYMS
+        if paged:
+            h = self.ctx.handle
+            freq_chunks = torch.empty(max(1, nch) * 256, dtype=torch.int32, device=dev)
+            check(L.lib().hf_symbol_stat_chunks_dev(h, C.c_void_p(_dev_ptr(data_in)), n, lay,
+                                                    C.c_void_p(freq_chunks.data_ptr())),
+                  "hf_symbol_stat_chunks_dev")
+            return self._pack_pages_shared(data_in, lay, cb, freq_chunks, payload, side, chunk_off,
+                                           sync)
         own_payload = payload is None
         if own_payload:
             # a codebook built from other counts than this tensor's (a global or foreign table,
@@ -604,6 +619,38 @@ class EntropyAwareHuffmanSystem(_Module):
                              chunk_off=chunk_off, side=side if lay == HF_LAYOUT_BF16_EXP else None,
                              codebook=cb, total_words=int(total.value) if sync else None)
 
+    def _pack_pages_shared(self, data_in, lay, cb, freq_chunks, payload, side, chunk_off,
+                           sync) -> EncodedStream:
+        n, dev = data_in.numel(), data_in.device
+        nch = (n + HF_CHUNK_SYMS - 1) // HF_CHUNK_SYMS
+        if chunk_off is None:
+            chunk_off = torch.empty(((nch + 1 + 3) // 4) * 4, dtype=torch.int32, device=dev)
+        if lay == HF_LAYOUT_BF16_EXP and side is None:
+            side = torch.empty(max(16, n), dtype=torch.uint8, device=dev)
+        total = C.c_uint64(0)
+
+        def run_pages(buf):
+            return L.lib().hf_encode_pages_shared(
+                self.ctx.handle, C.c_void_p(_dev_ptr(data_in)), n, lay, C.c_void_p(cb.ptr),
+                C.c_void_p(freq_chunks.data_ptr()), C.c_void_p(_dev_ptr(side)),
+                C.c_void_p(buf.data_ptr()), buf.numel(), C.c_void_p(chunk_off.data_ptr()),
+                C.byref(total) if sync else None)
+        own_payload = payload is None
+        if own_payload:
+            # (8 bits per symbol plus the page's header and region lengths; then the worst case)
+            payload = torch.empty(max(16, nch * (HF_CHUNK_SYMS // 4 + 64)), dtype=torch.int32,
+                                  device=dev)
+        rc = run_pages(payload)
+        if rc == L.HF_ERR_OVERFLOW and own_payload:
+            payload = torch.empty(max(16, int(L.lib().hf_pages_bound_words(n))),
+                                  dtype=torch.int32, device=dev)
+            rc = run_pages(payload)
+        check(rc, "hf_encode_pages_shared")
+        return EncodedStream(n=n, layout=lay, dtype=data_in.dtype, payload=payload,
+                             chunk_off=chunk_off, side=side if lay == HF_LAYOUT_BF16_EXP else None,
+                             codebook=cb, total_words=int(total.value) if sync else None,
+                             chunk_freq=freq_chunks, paged=True)
+
     # -- sub-field front end ---------------------------------------------------------------------
     def split_fields(self, data_in: torch.Tensor, layout: int):
         """``hf_fields_split``: (symbol bytes uint8[n], packed side stream uint8) of a tensor of
@@ -626,17 +673,21 @@ class EntropyAwareHuffmanSystem(_Module):
     # -- whole path ----------------------------------------------------------------------------
     def encode(self, data_in: torch.Tensor, mode: int = HF_MODE_AUTO,
                layout: Optional[int] = None, min_freq_threshold: int = 0,
-               slotted: bool = False) -> EncodedStream:
+               slotted: bool = False, paged: bool = False) -> EncodedStream:
         """``slotted``: one codebook for the stream, every chunk in a slot sized from the chunk's
-        own counts (``hf_encode_slotted``): 1.5-3 % more words, written faster, no container."""
+        own counts (``hf_encode_slotted``): 1.5-3 % more words, written faster.
+
+        ``paged``: one codebook for the stream, the chunks stored as pages without records
+        (``hf_encode_pages_shared``): exact sizes from the chunks' counts, no look-ahead words, no
+        look-back; decoded by four sub-decoders per page from tables made once per call."""
         data_in = data_in.contiguous()
         if layout in FIELD_LAYOUTS:
             sym, side = self.split_fields(data_in, layout)
-            s = self.encode(sym, mode, HF_LAYOUT_U8, min_freq_threshold, slotted)
+            s = self.encode(sym, mode, HF_LAYOUT_U8, min_freq_threshold, slotted, paged)
             s.layout, s.side, s.dtype = layout, side, data_in.dtype
             return s
-        if slotted:
-            return self._encode_slotted(data_in, mode, layout, min_freq_threshold)
+        if slotted or paged:
+            return self._encode_slotted(data_in, mode, layout, min_freq_threshold, paged)
         # one chunk: counted where the codebook is built (larger blocks may still ask for it, but a
         # block of one repeated symbol serialises the single counter array: kept to one chunk here)
         if data_in.numel() <= HF_CHUNK_SYMS:
@@ -647,7 +698,8 @@ class EntropyAwareHuffmanSystem(_Module):
         return self.encode_with(data_in, cb, layout)
 
     @_on_ctx_stream
-    def _encode_slotted(self, data_in, mode, layout, min_freq_threshold) -> EncodedStream:
+    def _encode_slotted(self, data_in, mode, layout, min_freq_threshold,
+                        paged: bool = False) -> EncodedStream:
         lay = layout_of(data_in) if layout is None else layout
         n, dev, h = data_in.numel(), data_in.device, self.ctx.handle
         nch = (n + HF_CHUNK_SYMS - 1) // HF_CHUNK_SYMS
@@ -666,6 +718,8 @@ class EntropyAwareHuffmanSystem(_Module):
         side = torch.empty(max(16, n), dtype=torch.uint8, device=dev) \
             if lay == HF_LAYOUT_BF16_EXP else None
         total = C.c_uint64(0)
+        if paged:
+            return self._pack_pages_shared(data_in, lay, cb, freq_chunks, None, side, chunk_off, True)
 
         def run(buf):
             return L.lib().hf_encode_slotted(
@@ -795,6 +849,8 @@ class EntropyAwareHuffmanSystem(_Module):
         lens = np.zeros(256, np.uint8)
         mode = C.c_int(0)
         ent = C.c_uint32(0)
+        if s.codebook is not None and s.chunk_codebooks is None:  # one table for every block
+            return s.codebook.download()
         if s.paged:  # read back from the page's own record
             check(L.lib().hf_page_codebook_download(
                 self.ctx.handle, C.c_void_p(s.payload.data_ptr()), s.payload.numel(),
@@ -871,6 +927,13 @@ class ParrallelHuffmanDecoder(_Module):  # spelling as in decoder/top_decoder.sc
             n_out = n_ids * HF_CHUNK_SYMS
         if out is None:
             out = torch.empty(max(n_out, 16), dtype=s.dtype, device=s.payload.device)
+        if s.paged and s.codebook is not None:
+            check(L.lib().hf_decode_pages_shared(
+                self.ctx.handle, C.c_void_p(s.payload.data_ptr()), s.payload.numel(),
+                C.c_void_p(s.chunk_off.data_ptr()), C.c_void_p(_dev_ptr(s.side)), s.n, s.layout,
+                C.c_void_p(s.codebook.ptr), C.c_void_p(_dev_ptr(chunk_ids)), None, n_ids,
+                C.c_void_p(_dev_ptr(out)), 0, 1 if check_stream else 0), "hf_decode_pages_shared")
+            return out[:n_out]
         if s.paged:
             check(L.lib().hf_decode_pages(
                 self.ctx.handle, C.c_void_p(s.payload.data_ptr()), s.payload.numel(),
@@ -907,6 +970,15 @@ class ParrallelHuffmanDecoder(_Module):  # spelling as in decoder/top_decoder.sc
         assert chunk_ids.numel() == out_slots.numel()
         assert page_pool.is_cuda and page_pool.is_contiguous() and page_pool.dtype == s.dtype
         assert page_pool.numel() % HF_CHUNK_SYMS == 0
+        if s.paged and s.codebook is not None:
+            check(L.lib().hf_decode_pages_shared(
+                self.ctx.handle, C.c_void_p(s.payload.data_ptr()), s.payload.numel(),
+                C.c_void_p(s.chunk_off.data_ptr()), C.c_void_p(_dev_ptr(s.side)), s.n, s.layout,
+                C.c_void_p(s.codebook.ptr), C.c_void_p(chunk_ids.data_ptr()),
+                C.c_void_p(out_slots.data_ptr()), chunk_ids.numel(),
+                C.c_void_p(page_pool.data_ptr()), page_pool.numel() // HF_CHUNK_SYMS,
+                1 if check_stream else 0), "hf_decode_pages_shared")
+            return page_pool
         if s.paged:
             check(L.lib().hf_decode_pages(
                 self.ctx.handle, C.c_void_p(s.payload.data_ptr()), s.payload.numel(),

@@ -27,6 +27,7 @@ struct hf_ctx {
     void* d_cbscratch;  // per-block codebook batch scratch, allocated on first use
     unsigned long long* d_scan_aux;  // group totals of the slot-offset scan, allocated on first use
     size_t scan_aux_bytes;
+    void* d_page_tab;   // decode tables of a stream-wide codebook for the page decoder (one call's)
     void* d_static_cbscratch;  // this device's copy of `scratch` below (never freed)
     int static_slot;           // slice of it this context holds, -1 before its first static call
     hipEvent_t ev0, ev1;
@@ -249,6 +250,7 @@ int hf_ctx_create(hf_ctx** out, int device, void* stream) {
     ok = ok && hipMalloc(&ctx->d_freq, 256 * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipHostMalloc(&ctx->h_freq, 256 * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipMalloc(&ctx->d_ctl, 64) == hipSuccess;
+    ok = ok && hipMalloc(&ctx->d_page_tab, hf_page_tab_image_bytes()) == hipSuccess;
     ok = ok && hipHostMalloc(&ctx->h_ctl, 64) == hipSuccess;
     ok = ok && hipMemset(ctx->d_ctl, 0, 64) == hipSuccess;  // ticket and the sticky error word
     // (the encoder's spill area, ~100 MB, is allocated by the first packed encode)
@@ -281,6 +283,7 @@ int hf_ctx_destroy(hf_ctx* ctx) {
     if (ctx->h_freq) (void)hipHostFree(ctx->h_freq);
     if (ctx->d_desc) (void)hipFree(ctx->d_desc);
     if (ctx->d_ctl) (void)hipFree(ctx->d_ctl);
+    if (ctx->d_page_tab) (void)hipFree(ctx->d_page_tab);
     if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
     if (ctx->d_spill) (void)hipFree(ctx->d_spill);
     if (ctx->d_cbscratch) (void)hipFree(ctx->d_cbscratch);
@@ -1017,16 +1020,18 @@ int hf_chunk_codebook_download(hf_ctx* ctx, const void* d_chunk_codebooks, uint6
 /* ---- paged stream (format version 2) ---------------------------------------------------------------- */
 uint64_t hf_pages_bound_words(uint64_t n) { return hf_num_chunks(n) * (uint64_t)HF_PAGE_MAX_WORDS; }
 
-int hf_encode_pages(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
-                    const void* d_chunk_codebooks, const uint32_t* d_freq_chunks, uint8_t* d_side,
-                    uint32_t* d_payload, uint64_t payload_cap_words, uint32_t* d_page_off,
-                    uint64_t* h_total_words) {
+static int encode_pages_common(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
+                               const void* d_chunk_codebooks, const void* d_codebook,
+                               const uint32_t* d_freq_chunks, uint8_t* d_side, uint32_t* d_payload,
+                               uint64_t payload_cap_words, uint32_t* d_page_off,
+                               uint64_t* h_total_words) {
+    const void* const cbp = d_codebook ? d_codebook : d_chunk_codebooks;
     if (!ctx || !d_page_off || !layout_ok(layout)) return HF_ERR_ARG;
-    if (n && (!d_data || !d_payload || !d_chunk_codebooks || !d_freq_chunks)) return HF_ERR_ARG;
+    if (n && (!d_data || !d_payload || !cbp || !d_freq_chunks)) return HF_ERR_ARG;
     const int lay = norm_layout(layout);
     if (lay == HF_LAYOUT_BF16_EXP && n && !d_side) return HF_ERR_ARG;
     if (!aligned16(d_data) || !aligned16(d_side) || !aligned16(d_payload) ||
-        !aligned16(d_page_off) || !aligned16(d_chunk_codebooks) || !aligned16(d_freq_chunks))
+        !aligned16(d_page_off) || !aligned16(cbp) || !aligned16(d_freq_chunks))
         return HF_ERR_ALIGN;
     if (n > (1ull << 40)) return HF_ERR_RANGE;
     HF_USE_DEVICE(ctx);
@@ -1037,8 +1042,9 @@ int hf_encode_pages(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
     } else {
         tic(ctx);
         hf_launch_encode_pages(d_data, n, lay, reinterpret_cast<const hf_chunk_cb*>(d_chunk_codebooks),
-                               d_freq_chunks, d_side, d_payload, payload_cap_words, d_page_off,
-                               ctx->d_scan_aux, ctx->d_ctl + 1, ctx->stream);
+                               reinterpret_cast<const hf_cb_dev*>(d_codebook), d_freq_chunks, d_side,
+                               d_payload, payload_cap_words, d_page_off, ctx->d_scan_aux,
+                               ctx->d_ctl + 1, ctx->stream);
         const hipError_t launch_err = hipGetLastError();
         toc(ctx);
         HF_HIP(launch_err);
@@ -1053,10 +1059,29 @@ int hf_encode_pages(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
     return HF_OK;
 }
 
-int hf_decode_pages(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
-                    const uint32_t* d_page_off, const uint8_t* d_side, uint64_t n, int layout,
-                    const uint32_t* d_page_ids, const uint32_t* d_out_slots, uint64_t n_ids,
-                    void* d_out, uint64_t n_slots, int check) {
+int hf_encode_pages(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
+                    const void* d_chunk_codebooks, const uint32_t* d_freq_chunks, uint8_t* d_side,
+                    uint32_t* d_payload, uint64_t payload_cap_words, uint32_t* d_page_off,
+                    uint64_t* h_total_words) {
+    if (n && !d_chunk_codebooks) return HF_ERR_ARG;
+    return encode_pages_common(ctx, d_data, n, layout, d_chunk_codebooks, nullptr, d_freq_chunks,
+                               d_side, d_payload, payload_cap_words, d_page_off, h_total_words);
+}
+
+int hf_encode_pages_shared(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
+                           const void* d_codebook, const uint32_t* d_freq_chunks, uint8_t* d_side,
+                           uint32_t* d_payload, uint64_t payload_cap_words, uint32_t* d_page_off,
+                           uint64_t* h_total_words) {
+    if (!d_codebook) return HF_ERR_ARG;
+    return encode_pages_common(ctx, d_data, n, layout, nullptr, d_codebook, d_freq_chunks, d_side,
+                               d_payload, payload_cap_words, d_page_off, h_total_words);
+}
+
+static int decode_pages_common(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
+                               const uint32_t* d_page_off, const uint8_t* d_side, uint64_t n,
+                               int layout, const void* d_codebook, const uint32_t* d_page_ids,
+                               const uint32_t* d_out_slots, uint64_t n_ids, void* d_out,
+                               uint64_t n_slots, int check) {
     if (!ctx || !layout_ok(layout)) return HF_ERR_ARG;
     if (d_out_slots && !d_page_ids) return HF_ERR_ARG;
     const uint64_t n_work = d_page_ids ? n_ids : hf_num_chunks(n);
@@ -1064,14 +1089,16 @@ int hf_decode_pages(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_wor
     const int lay = norm_layout(layout);
     if (lay == HF_LAYOUT_BF16_EXP && n_work && !d_side) return HF_ERR_ARG;
     if (!aligned16(d_payload) || !aligned16(d_side) || !aligned16(d_out) || !aligned16(d_page_off) ||
-        !aligned16(d_page_ids) || !aligned16(d_out_slots))
+        !aligned16(d_page_ids) || !aligned16(d_out_slots) || !aligned16(d_codebook))
         return HF_ERR_ALIGN;
     if (n > (1ull << 40) || n_work > 0x7FFFFFFFull || n_slots > 0xFFFFFFFFull) return HF_ERR_RANGE;
     HF_USE_DEVICE(ctx);
     if (n_work) {
         tic(ctx);
-        hf_launch_decode_pages(d_payload, payload_words, d_page_off, d_side, n, lay, d_page_ids,
-                               d_out_slots, n_slots, n_ids, d_out, ctx->d_ctl + 1, ctx->stream);
+        hf_launch_decode_pages(d_payload, payload_words, d_page_off, d_side, n, lay,
+                               reinterpret_cast<const hf_cb_dev*>(d_codebook), ctx->d_page_tab,
+                               d_page_ids, d_out_slots, n_slots, n_ids, d_out, ctx->d_ctl + 1,
+                               ctx->stream);
         const hipError_t launch_err = hipGetLastError();
         toc(ctx);
         HF_HIP(launch_err);
@@ -1082,6 +1109,24 @@ int hf_decode_pages(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_wor
         return report_kernel_errors(ctx);
     }
     return HF_OK;
+}
+
+int hf_decode_pages(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
+                    const uint32_t* d_page_off, const uint8_t* d_side, uint64_t n, int layout,
+                    const uint32_t* d_page_ids, const uint32_t* d_out_slots, uint64_t n_ids,
+                    void* d_out, uint64_t n_slots, int check) {
+    return decode_pages_common(ctx, d_payload, payload_words, d_page_off, d_side, n, layout, nullptr,
+                               d_page_ids, d_out_slots, n_ids, d_out, n_slots, check);
+}
+
+int hf_decode_pages_shared(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
+                           const uint32_t* d_page_off, const uint8_t* d_side, uint64_t n, int layout,
+                           const void* d_codebook, const uint32_t* d_page_ids,
+                           const uint32_t* d_out_slots, uint64_t n_ids, void* d_out,
+                           uint64_t n_slots, int check) {
+    if (!d_codebook) return HF_ERR_ARG;
+    return decode_pages_common(ctx, d_payload, payload_words, d_page_off, d_side, n, layout,
+                               d_codebook, d_page_ids, d_out_slots, n_ids, d_out, n_slots, check);
 }
 
 // The record of a stored page, read back and expanded on the host: ranks the record lists, then
@@ -1199,7 +1244,6 @@ bool plan_container(uint64_t n, int layout, int kind, int placement, uint64_t pa
     if (placement != HF_PLACEMENT_DENSE && placement != HF_PLACEMENT_SLOTTED &&
         placement != HF_PLACEMENT_PAGED)
         return false;
-    if (placement == HF_PLACEMENT_PAGED && kind != HF_CODEBOOK_PER_CHUNK) return false;
     if (layout == HF_LAYOUT_BITPLANE8 && n % 8 != 0) return false;
     if (n > (1ull << 40) || payload_words > 0xFFFFFFFFull) return false;
     const uint64_t nchunks = hf_num_chunks(n);
@@ -1214,7 +1258,8 @@ bool plan_container(uint64_t n, int layout, int kind, int placement, uint64_t pa
     info->nchunks = nchunks;
     info->payload_words = payload_words;
     uint64_t off = HF_CONTAINER_HEADER_BYTES;
-    if (placement != HF_PLACEMENT_PAGED) {
+    // (pages with records carry their codebooks; pages without are coded with the stream's one)
+    if (placement != HF_PLACEMENT_PAGED || kind == HF_CODEBOOK_STREAM) {
         info->off_codebook = off;
         off += kind == HF_CODEBOOK_STREAM ? 768ull : nchunks * HF_CONTAINER_CHUNK_CODEBOOK_BYTES;
         off = up16(off);
@@ -1409,7 +1454,7 @@ int hf_container_codebook(hf_ctx* ctx, const void* d_blob, const hf_container_in
                         info->payload_words, &pl) ||
         pl.off_codebook != info->off_codebook)
         return HF_ERR_ARG;
-    if (pl.placement == HF_PLACEMENT_PAGED) return HF_OK;  // the records are in the pages
+    if (!pl.off_codebook) return HF_OK;  // paged with records: the codebooks are in the pages
     if (!d_codebook_out) return HF_ERR_ARG;
     HF_USE_DEVICE(ctx);
     const uint8_t* blob = reinterpret_cast<const uint8_t*>(d_blob);

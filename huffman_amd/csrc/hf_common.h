@@ -161,12 +161,14 @@ void hf_launch_wire_to_cb(const hf_wire_chunk_cb* in, uint64_t nchunks, hf_chunk
 void hf_launch_scan_u32(uint32_t* d_a, uint64_t m, unsigned long long* d_aux,
                         unsigned long long limit, uint32_t* d_err, hipStream_t s);
 void hf_launch_encode_pages(const void* d_data, uint64_t n, int layout, const hf_chunk_cb* cbs,
-                            const uint32_t* d_freq_chunks, uint8_t* d_side, uint32_t* d_payload,
-                            uint64_t cap_words, uint32_t* d_page_off,
+                            const hf_cb_dev* shared_cb, const uint32_t* d_freq_chunks, uint8_t* d_side,
+                            uint32_t* d_payload, uint64_t cap_words, uint32_t* d_page_off,
                             unsigned long long* d_scan_aux, uint32_t* d_err, hipStream_t s);
+size_t hf_page_tab_image_bytes(void);
 void hf_launch_decode_pages(const uint32_t* d_payload, uint64_t payload_words,
                             const uint32_t* d_page_off, const uint8_t* d_side, uint64_t n,
-                            int layout, const uint32_t* d_page_ids, const uint32_t* d_out_slots,
+                            int layout, const hf_cb_dev* shared_cb, void* d_tab_image,
+                            const uint32_t* d_page_ids, const uint32_t* d_out_slots,
                             uint64_t n_slots, uint64_t n_ids, void* d_out, uint32_t* d_err,
                             hipStream_t s);
 uint64_t hf_fields_side_bytes_impl(uint64_t n, int layout);

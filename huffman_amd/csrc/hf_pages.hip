@@ -20,10 +20,13 @@
 // in rank order as far as the order is not plain ascending, and the number of ranks per code
 // length.  Everything a reader needs for one page lies in one contiguous piece of the payload.
 //
+// A stream whose pages share ONE codebook (the stream-wide one of hf_system_codebook_dev) stores
+// pages without a record: word 0 = B << 10 | 1 << 29, the region lengths, the strings.  Its decoder
+// copies ready-made tables (built once per call from the codebook) into LDS instead of building
+// them per page.
+//
 // HBM traffic per byte symbol: encode 1 B read + L/8 B written (+ 2.3 KB per page of counts and
 // codebook read for the sizes), decode L/8 B read + 1 B written.
-#include <stdlib.h>
-
 #include "hf_common.h"
 #include "hf_dec_tables.h"
 
@@ -41,6 +44,11 @@ constexpr int kImgSlack = 40;  // reads of a lane's window may run this far past
 
 __host__ __device__ __forceinline__ uint32_t page_words(const uint32_t head, const uint32_t bits) {
     return kHdr + (head + 3u) / 4u + kGap + (bits + 31u) / 32u;
+}
+
+constexpr uint32_t kSharedFlag = 1u << 29;  // word 0 of a page without a record
+__host__ __device__ __forceinline__ uint32_t page_words_shared(const uint32_t bits) {
+    return 1u + kGap + (bits + 31u) / 32u;
 }
 
 // ranks a record lists explicitly: the largest p with rank2sym[p-1] >= rank2sym[p], else 0 (from
@@ -86,6 +94,27 @@ __global__ __launch_bounds__(256) void hf_k_page_sizes(const uint32_t* __restric
     bits = bits < most ? bits : most;
     const uint32_t head = head_of_wave(reinterpret_cast<const uint32_t*>(cb->rank2sym)[lane], lane);
     if (lane == 0) size[c] = page_words(head, bits);
+}
+
+// the same for pages without a record, all coded with the stream's codebook
+__global__ __launch_bounds__(256) void hf_k_page_sizes_shared(const uint32_t* __restrict__ freq_chunks,
+                                                              const hf_cb_dev* __restrict__ cb,
+                                                              const uint32_t nchunks,
+                                                              uint32_t* __restrict__ size) {
+    const int lane = hf_lane();
+    const uint32_t c = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (c > nchunks) return;
+    if (c == nchunks) {
+        if (lane == 0) size[c] = 0;
+        return;
+    }
+    const uint4 f = reinterpret_cast<const uint4*>(freq_chunks + (size_t)c * 256)[lane];
+    const uint4 e = reinterpret_cast<const uint4*>(cb->enc)[lane];
+    uint32_t bits = f.x * (e.x >> 16) + f.y * (e.y >> 16) + f.z * (e.z >> 16) + f.w * (e.w >> 16);
+    bits = hf_wave_sum_u32(bits);
+    const uint32_t most = HF_CHUNK_SYMS * (uint32_t)HF_MAX_CODE_LEN;
+    bits = bits < most ? bits : most;
+    if (lane == 0) size[c] = page_words_shared(bits);
 }
 
 // ---- encoder ---------------------------------------------------------------------------------
@@ -258,8 +287,10 @@ __device__ __forceinline__ void emit_string(const uint32_t (&comb)[32], const ui
     if (ab != 0u) put(lo << (32u - ab));
 }
 
-template <int LAYOUT, bool FULL>
+// SHARED: a page without a record; `enc_tab` is then the stream codebook's table and cb is null
+template <int LAYOUT, bool FULL, bool SHARED>
 __device__ __forceinline__ void encode_page(EncPageLds& L, const void* chunk_in, uint8_t* side_chunk,
+                                            const uint32_t* __restrict__ enc_tab,
                                             const hf_chunk_cb* __restrict__ cb, const uint32_t nvalid,
                                             uint32_t* __restrict__ payload, const uint32_t off0,
                                             const uint32_t words, uint32_t* err) {
@@ -272,17 +303,20 @@ __device__ __forceinline__ void encode_page(EncPageLds& L, const void* chunk_in,
 
     uint32_t sy[16];
     load_string<LAYOUT, FULL>(chunk_in, side_chunk, q, lane, nvalid, sy);
-    L.enc[tid] = cb->enc[tid];
-    if (tid < 64) reinterpret_cast<uint32_t*>(L.r2s)[tid] = reinterpret_cast<const uint32_t*>(cb->rank2sym)[tid];
-    else if (tid < 128) reinterpret_cast<uint32_t*>(L.lbr)[tid - 64] = reinterpret_cast<const uint32_t*>(cb->len_by_rank)[tid - 64];
+    constexpr uint32_t hdr0 = SHARED ? 1u : kHdr;  // words in front of the listed symbols
+    L.enc[tid] = enc_tab[tid];
     uint32_t mode = 0, entropy = 0;
-    if (tid == 127) {
-        mode = cb->mode;
-        entropy = cb->entropy_q16;
+    if (!SHARED) {
+        if (tid < 64) reinterpret_cast<uint32_t*>(L.r2s)[tid] = reinterpret_cast<const uint32_t*>(cb->rank2sym)[tid];
+        else if (tid < 128) reinterpret_cast<uint32_t*>(L.lbr)[tid - 64] = reinterpret_cast<const uint32_t*>(cb->len_by_rank)[tid - 64];
+        if (tid == 127) {
+            mode = cb->mode;
+            entropy = cb->entropy_q16;
+        }
     }
     {
         // the image is OR-ed into: zero what the page covers (the whole header part otherwise)
-        const uint32_t upto = in_lds ? a0 + words : a0 + kHdr + 64u + kGap;
+        const uint32_t upto = in_lds ? a0 + words : a0 + hdr0 + (SHARED ? 0u : 64u) + kGap;
         for (uint32_t k = tid; k * 4u < upto + 4u; k += 256u)
             reinterpret_cast<uint4*>(L.img)[k] = make_uint4(0, 0, 0, 0);
     }
@@ -293,18 +327,23 @@ __device__ __forceinline__ void encode_page(EncPageLds& L, const void* chunk_in,
     {
         const uint32_t t = join_string<FULL>(sy, q, lane, nvalid, tab, comb, clp);
         L.tlen[tid] = t;
-        const bool desc = tid > 0 && L.r2s[tid - 1] >= L.r2s[tid];
-        const u64 m = __ballot(desc);
-        if (lane == 0) L.red[q] = m ? q * 64u + 63u - (uint32_t)__builtin_clzll(m) : 0u;
+        if (!SHARED) {
+            const bool desc = tid > 0 && L.r2s[tid - 1] >= L.r2s[tid];
+            const u64 m = __ballot(desc);
+            if (lane == 0) L.red[q] = m ? q * 64u + 63u - (uint32_t)__builtin_clzll(m) : 0u;
+        }
     }
     __syncthreads();
 
-    uint32_t head = L.red[0];
+    uint32_t head = 0;
+    if (!SHARED) {
+        head = L.red[0];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) head = L.red[w] > head ? L.red[w] : head;
-    head = (uint32_t)__builtin_amdgcn_readfirstlane((int)head);
+        for (int w = 1; w < 4; ++w) head = L.red[w] > head ? L.red[w] : head;
+        head = (uint32_t)__builtin_amdgcn_readfirstlane((int)head);
+    }
     const uint32_t hw = (head + 3u) / 4u;
-    uint32_t* const gap = L.img + a0 + kHdr + hw;
+    uint32_t* const gap = L.img + a0 + hdr0 + hw;
     if (q < 2) {
         // region lengths, their prefix sum, the length table
         const uint32_t R = L.tlen[tid] + L.tlen[tid + 128];
@@ -323,11 +362,11 @@ __device__ __forceinline__ void encode_page(EncPageLds& L, const void* chunk_in,
                                   __HIP_MEMORY_SCOPE_WORKGROUP);
         if (tid == 127) {
             L.rstart[128] = incl;
-            L.img[a0] = head | ((mode & 1u) << 9) | (incl << 10);
-            L.img[a0 + 1] = entropy;
+            L.img[a0] = SHARED ? (incl << 10) | kSharedFlag : head | ((mode & 1u) << 9) | (incl << 10);
+            if (!SHARED) L.img[a0 + 1] = entropy;
         }
     }
-    {
+    if (!SHARED) {
         // number of ranks per code length, 16-bit fields two to a word
         const uint32_t len = L.lbr[tid];
 #pragma unroll
@@ -343,13 +382,13 @@ __device__ __forceinline__ void encode_page(EncPageLds& L, const void* chunk_in,
 
     const uint32_t B = L.rstart[128];
     // counts that were not this page's: the page would not have the size its place was cut for
-    const bool fits = page_words(head, B) == words;
+    const bool fits = (SHARED ? page_words_shared(B) : page_words(head, B)) == words;
     if (!fits) {
         if (tid == 0) atomicOr(err, HF_KERR_CORRUPT);
         return;  // (the same in every thread)
     }
     const uint32_t wn = (B + 31u) / 32u;
-    const uint32_t hdr_words = kHdr + hw + kGap;
+    const uint32_t hdr_words = hdr0 + hw + kGap;
     uint32_t* const img_str = L.img + a0 + hdr_words;
     uint32_t* const glob_str = payload + off0 + hdr_words;
     if (!in_lds) {
@@ -386,10 +425,11 @@ __device__ __forceinline__ void encode_page(EncPageLds& L, const void* chunk_in,
     }
 }
 
-template <int LAYOUT>
+// cbp: the per-page records (hf_chunk_cb[nchunks]), or the stream's codebook (hf_cb_dev) when SHARED
+template <int LAYOUT, bool SHARED>
 __global__ __launch_bounds__(256) void hf_k_encode_pages(
     const void* __restrict__ data, const uint64_t n, const uint32_t nchunks,
-    const hf_chunk_cb* __restrict__ cbs, uint8_t* __restrict__ side, uint32_t* __restrict__ payload,
+    const void* __restrict__ cbp, uint8_t* __restrict__ side, uint32_t* __restrict__ payload,
     const uint32_t* __restrict__ page_off, const u64* __restrict__ total_words, const u64 limit,
     uint32_t* err) {
     __shared__ __attribute__((aligned(1024))) EncPageLds L;
@@ -409,10 +449,14 @@ __global__ __launch_bounds__(256) void hf_k_encode_pages(
     const uint32_t nvalid = left < HF_CHUNK_SYMS ? (uint32_t)left : HF_CHUNK_SYMS;
     const void* chunk_in = reinterpret_cast<const uint8_t*>(data) + first * elem_bytes;
     uint8_t* side_chunk = side ? side + first : nullptr;
+    const hf_chunk_cb* const cb = SHARED ? nullptr : reinterpret_cast<const hf_chunk_cb*>(cbp) + c;
+    const uint32_t* const enc_tab = SHARED ? reinterpret_cast<const hf_cb_dev*>(cbp)->enc : cb->enc;
     if (nvalid == HF_CHUNK_SYMS)
-        encode_page<LAYOUT, true>(L, chunk_in, side_chunk, cbs + c, nvalid, payload, off0, off1 - off0, err);
+        encode_page<LAYOUT, true, SHARED>(L, chunk_in, side_chunk, enc_tab, cb, nvalid, payload, off0,
+                                          off1 - off0, err);
     else
-        encode_page<LAYOUT, false>(L, chunk_in, side_chunk, cbs + c, nvalid, payload, off0, off1 - off0, err);
+        encode_page<LAYOUT, false, SHARED>(L, chunk_in, side_chunk, enc_tab, cb, nvalid, payload, off0,
+                                           off1 - off0, err);
 }
 
 // ---- decoder ---------------------------------------------------------------------------------
@@ -440,19 +484,31 @@ __device__ __forceinline__ uint32_t lane_value(const uint32_t v, const uint32_t 
     return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
 }
 
+// The decode tables of one codebook as they lie in LDS -- and, for a stream with one codebook, in
+// global memory, ready to be copied in 16-byte pieces (hf_k_page_tab_image makes that copy once
+// per call).
 template <int BITS>
-struct DecPageLds {
+struct DecTabLds {
     uint16_t lut[1 << BITS];  // first: the lookup ORs the table's address into the index
-    uint32_t img[kImgWords + kImgSlack];
     uint16_t tail[512];
     uint8_t r2s[256];
-    uint32_t present[8];
     uint32_t cls[20];  // [d]: ranks with codes of at most d bits << 17 | their share of the code space
+    uint32_t tail_n, tail_start;  // the direct table's span of the code space (tail_n = 0: none)
+    uint32_t valid;               // (image only) the codebook is canonical and its tables are complete
+    uint32_t pad;
+};
+static_assert(sizeof(DecTabLds<11>) % 16 == 0, "copied in 16-byte pieces");
+
+template <int BITS>
+struct DecPageLds {
+    DecTabLds<BITS> tab;
+    uint32_t img[kImgWords + kImgSlack];
+    uint32_t present[8];
     // first bit of region r ([128] = the sum of the region lengths); once every thread has taken
     // its two values (before the last barrier in front of the symbol loop) the backward strings'
     // bit counts are handed to the forward ones through the same words
     uint32_t rstart[132];
-    uint32_t red[8];
+    uint32_t red[4];
 };
 
 // Tables of one page, shared by its four wavefronts: a first level of BITS bits (entry: symbol
@@ -661,15 +717,139 @@ __device__ __forceinline__ uint32_t decode_string_slow(const bool back, const ui
     return taken * 32u - (uint32_t)(32 - room) - sh;
 }
 
-template <int LAYOUT, int BITS, bool PAIRCHECK>
+// ranks with at most d bits (<< 17) and the code space they fill, for d = 0 .. 16, from the number
+// of ranks per length (lane d - 1 holds that of length d); lanes 0 .. 16 of wavefront 0 write
+// cls[].  Returns the inclusive scan of the counts (lane d - 1: ranks with at most d bits); total
+// and kraft are the scans' last values.
+__device__ __forceinline__ uint32_t class_bounds(const uint32_t cnt, const int lane, const uint32_t q,
+                                                 uint32_t* cls, uint32_t& total, uint32_t& kraft) {
+    const uint32_t cumv = row_scan_incl(cnt);
+    const uint32_t csv = row_scan_incl(cnt << (15 - (lane & 15)));
+    total = lane_value(cumv, 15);
+    kraft = lane_value(csv, 15);
+    if (q == 0 && lane <= 16) {
+        // cls[d] for d = 0 .. 16 (lane d takes the values of lane d - 1)
+        const uint32_t pc = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)((cumv << 17) | csv), 0x111,
+                                                                  0xF, 0xF, true);
+        cls[lane] = lane == 16 ? (total << 17) | kraft : pc;
+    }
+    return cumv;
+}
+
+// Thread `tid` fills the span of rank tid (code length my_len, symbol r2s[tid]) in the first level
+// or in the direct table of the longer codes; cls[] and r2s[] are complete, the tables zeroed.
+// Returns the rank's left-aligned 16-bit code.
+template <int BITS>
+__device__ __forceinline__ uint32_t fill_tables(DecTabLds<BITS>& D, const uint32_t tid,
+                                                const uint32_t my_len, const uint32_t kraft,
+                                                uint32_t& tail_n, uint32_t& tail_start) {
+    const uint32_t pc = D.cls[my_len - 1];
+    const uint32_t my_start = (pc & 0x1FFFFu) + ((tid - (pc >> 17)) << (16u - my_len));
+    const uint32_t val = ((uint32_t)D.r2s[tid] << 8) | my_len;
+    const uint32_t v2 = val | (val << 16);
+    // (a code's span starts at a multiple of its size: the widest aligned store that fits)
+    auto fill = [&](uint16_t* to, const uint32_t at, const uint32_t span) {
+        if (span >= 8) {
+            for (uint32_t i = 0; i < span; i += 8)
+                *reinterpret_cast<uint4*>(to + at + i) = make_uint4(v2, v2, v2, v2);
+        } else if (span == 4) {
+            *reinterpret_cast<uint2*>(to + at) = make_uint2(v2, v2);
+        } else if (span == 2) {
+            *reinterpret_cast<uint32_t*>(to + at) = v2;
+        } else {
+            to[at] = (uint16_t)val;
+        }
+    };
+    tail_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)(D.cls[BITS] & 0x1FFFFu));
+    const uint32_t tail_span = kraft - tail_start;
+    tail_n = tail_span <= 512u ? tail_span : 0u;
+    if (my_len <= (uint32_t)BITS)
+        fill(D.lut, my_start >> (16 - BITS), 1u << (BITS - my_len));
+    else if (tail_n != 0)
+        fill(D.tail, my_start - tail_start, 1u << (16u - my_len));
+    return my_start;
+}
+
+// The table image of a stream-wide codebook: ranks from the left-aligned codes (canonical codes
+// ascend with the rank), ranks per length, then the fill every page decoder does.  valid = 0 when
+// the codes are not the canonical ones of their lengths (an uploaded table of another shape): the
+// page decoder then reports every page.
+template <int BITS>
+__global__ __launch_bounds__(256) void hf_k_page_tab_image(const hf_cb_dev* __restrict__ cb,
+                                                           DecTabLds<BITS>* __restrict__ out) {
+    __shared__ __attribute__((aligned(2 << BITS))) DecTabLds<BITS> D;
+    __shared__ uint32_t key[256];
+    __shared__ uint32_t cnt[16];
+    __shared__ uint8_t lbr[256];
+    __shared__ uint32_t bad;
+    const int lane = hf_lane();
+    const uint32_t tid = threadIdx.x;
+    const uint32_t q = tid >> 6;
+#pragma unroll
+    for (int j = 0; j < (2 << BITS) / 16 / 256; ++j)
+        reinterpret_cast<uint4*>(D.lut)[tid + 256 * j] = make_uint4(0, 0, 0, 0);
+    if (tid < 64) reinterpret_cast<uint4*>(D.tail)[tid] = make_uint4(0, 0, 0, 0);
+    if (tid < 16) cnt[tid] = 0;
+    if (tid == 0) bad = 0;
+    const uint32_t e = cb->enc[tid];
+    const uint32_t len = e >> 16, code = e & 0xFFFFu;
+    const bool used = len >= 1 && len <= HF_MAX_CODE_LEN;
+    const uint32_t mine = used ? code << (16u - len) : 0x10000u + tid;  // unused symbols rank last
+    key[tid] = mine;
+    D.r2s[tid] = 0;
+    lbr[tid] = 0;
+    __syncthreads();
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < 256; ++j) rank += key[j] < mine ? 1u : 0u;
+    if (used) {
+        // (two symbols with one code would take one rank: caught by the start check below)
+        D.r2s[rank] = (uint8_t)tid;
+        lbr[rank] = (uint8_t)len;
+        atomicAdd(&cnt[len - 1], 1u);
+    }
+    __syncthreads();
+    uint32_t total, kraft;
+    class_bounds(lane < 16 ? cnt[lane & 15] : 0u, lane, q, D.cls, total, kraft);
+    __syncthreads();
+    uint32_t tail_n = 0, tail_start = 0;
+    const uint32_t my_len = lbr[tid];
+    if (kraft <= 65536u && tid < total) {
+        // the canonical code of rank tid must be the symbol's own code: only then is the span the
+        // fill writes known to lie inside the tables
+        const uint32_t pc = D.cls[my_len ? my_len - 1 : 0];
+        const uint32_t start = (pc & 0x1FFFFu) + ((tid - (pc >> 17)) << (16u - my_len));
+        if (my_len == 0 || tid < (pc >> 17) || start != key[D.r2s[tid]])
+            atomicOr(&bad, 1u);
+        else
+            fill_tables<BITS>(D, tid, my_len, kraft, tail_n, tail_start);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        tail_start = D.cls[BITS] & 0x1FFFFu;
+        const uint32_t span = kraft - tail_start;
+        D.tail_n = kraft <= 65536u && span <= 512u ? span : 0u;
+        D.tail_start = tail_start;
+        D.valid = (kraft <= 65536u && total >= 1u && bad == 0u) ? 1u : 0u;
+        D.pad = 0;
+    }
+    __syncthreads();
+    constexpr uint32_t kPieces = sizeof(DecTabLds<BITS>) / 16;
+    for (uint32_t g = tid; g < kPieces; g += 256u)
+        reinterpret_cast<uint4*>(out)[g] = reinterpret_cast<const uint4*>(&D)[g];
+}
+
+// One workgroup per page.  SHARED: the pages carry no record and `tabimg` holds the tables of the
+// stream's codebook.
+template <int LAYOUT, int BITS, bool PAIRCHECK, bool SHARED>
 __global__ __launch_bounds__(256) void hf_k_decode_pages(
     const uint32_t* __restrict__ payload, const uint32_t payload_words,
     const uint32_t* __restrict__ page_off, const uint8_t* __restrict__ side, const uint64_t n,
     const uint32_t nchunks, const uint32_t* __restrict__ page_ids,
     const uint32_t* __restrict__ out_slots, const uint32_t n_slots, void* __restrict__ out,
-    uint32_t* err) {
+    const DecTabLds<BITS>* __restrict__ tabimg, uint32_t* err) {
     typedef PageTables<BITS, PAIRCHECK> Tab;
     __shared__ __attribute__((aligned(2 << BITS))) DecPageLds<BITS> L;
+    constexpr uint32_t hdr0 = SHARED ? 1u : kHdr;
     const int lane = hf_lane();
     const uint32_t tid = threadIdx.x;
     const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
@@ -686,7 +866,7 @@ __global__ __launch_bounds__(256) void hf_k_decode_pages(
     const uint64_t first = (uint64_t)c * HF_CHUNK_SYMS;
     const uint64_t left = n - first;
     const uint32_t nvalid = left < HF_CHUNK_SYMS ? (uint32_t)left : HF_CHUNK_SYMS;
-    if (off1 < off0 || off1 > payload_words || off1 - off0 < kHdr + kGap ||
+    if (off1 < off0 || off1 > payload_words || off1 - off0 < hdr0 + kGap ||
         off1 - off0 > HF_PAGE_MAX_WORDS || (page_ids && nvalid != HF_CHUNK_SYMS))
         return bad();
     const uint32_t words = off1 - off0;
@@ -697,7 +877,7 @@ __global__ __launch_bounds__(256) void hf_k_decode_pages(
     // per thread and step, all steps requested before the first is used; the buffer's last, partial
     // piece (a buffer whose size is not a multiple of 16 bytes) is fetched word by word
     constexpr int kSteps = (kImgWords + 1023) / 1024;
-    const uint32_t nload = in_lds ? a0 + words : a0 + kHdr + 64u + kGap;
+    const uint32_t nload = in_lds ? a0 + words : a0 + hdr0 + (SHARED ? 0u : 64u) + kGap;
     const uint32_t whole = payload_words & ~3u;
     uint4 v[kSteps];
 #pragma unroll
@@ -717,57 +897,74 @@ __global__ __launch_bounds__(256) void hf_k_decode_pages(
             }
         }
     }
-    // cleared tables: first-level entries no short code covers say "longer", tail entries no code
-    // covers match nothing
+    if (SHARED) {
+        // the stream's tables, ready-made
+        constexpr uint32_t kPieces = sizeof(DecTabLds<BITS>) / 16;
 #pragma unroll
-    for (int j = 0; j < (2 << BITS) / 16 / 256; ++j)
-        reinterpret_cast<uint4*>(L.lut)[tid + 256 * j] = make_uint4(0, 0, 0, 0);
-    if (tid < 64) reinterpret_cast<uint4*>(L.tail)[tid] = make_uint4(0, 0, 0, 0);
-    if (tid < 8) L.present[tid] = 0u;
+        for (uint32_t j = 0; j < (kPieces + 255u) / 256u; ++j) {
+            const uint32_t g = tid + 256u * j;
+            if (g < kPieces) reinterpret_cast<uint4*>(&L.tab)[g] = reinterpret_cast<const uint4*>(tabimg)[g];
+        }
+    } else {
+        // cleared tables: first-level entries no short code covers say "longer", tail entries no
+        // code covers match nothing
+#pragma unroll
+        for (int j = 0; j < (2 << BITS) / 16 / 256; ++j)
+            reinterpret_cast<uint4*>(L.tab.lut)[tid + 256 * j] = make_uint4(0, 0, 0, 0);
+        if (tid < 64) reinterpret_cast<uint4*>(L.tab.tail)[tid] = make_uint4(0, 0, 0, 0);
+        if (tid < 8) L.present[tid] = 0u;
+    }
     reinterpret_cast<uint4*>(L.img)[tid] = v[0];
     __syncthreads();
 
-    // ---- the record ----
+    // ---- the header (and the record) ----
     const uint32_t hdr = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.img[a0]);
-    const uint32_t head = hdr & 0x1FFu, B = hdr >> 10;
-    if ((hdr >> 29) != 0u || head > 255u || page_words(head, B) != words) return bad();
+    const uint32_t head = SHARED ? 0u : hdr & 0x1FFu;
+    const uint32_t B = SHARED ? (hdr >> 10) & 0x7FFFFu : hdr >> 10;
+    if (SHARED) {
+        if ((hdr >> 29) != 1u || (hdr & 0x3FFu) != 0u || page_words_shared(B) != words || L.tab.valid != 1u)
+            return bad();
+    } else {
+        if ((hdr >> 29) != 0u || head > 255u || page_words(head, B) != words) return bad();
+    }
     const uint32_t hw = (head + 3u) / 4u;
-    // Lengths never decrease with the rank and the codes of one length tile the left-aligned 16-bit
-    // code space one after the other.  Lane d - 1 takes length d: ranks with at most d bits (cum)
-    // and the code space they fill (cs), by two scans over 16 lanes; rank tid then has the smallest
-    // length whose cum exceeds it -- one compare against each of 15 scalars.
-    const uint32_t cnt = lane < 16 ? reinterpret_cast<const uint16_t*>(L.img + a0 + 2)[lane] : 0u;
-    const uint32_t cumv = row_scan_incl(cnt);
-    const uint32_t csv = row_scan_incl(cnt << (15 - (lane & 15)));
-    const uint32_t total = lane_value(cumv, 15), kraft = lane_value(csv, 15);
-    if (total != 256u || kraft > 65536u) return bad();
-    uint32_t my_len = 1;
+    uint32_t my_len = 1, kraft = 0;
+    if (!SHARED) {
+        // Lengths never decrease with the rank and the codes of one length tile the left-aligned
+        // 16-bit code space one after the other.  Lane d - 1 takes length d: ranks with at most d
+        // bits (cum) and the code space they fill (cs), by two scans over 16 lanes; rank tid then
+        // has the smallest length whose cum exceeds it -- one compare against each of 15 scalars.
+        const uint32_t cnt = lane < 16 ? reinterpret_cast<const uint16_t*>(L.img + a0 + 2)[lane] : 0u;
+        uint32_t total;
+        const uint32_t cumv = class_bounds(cnt, lane, q, L.tab.cls, total, kraft);
+        if (total != 256u || kraft > 65536u) return bad();
 #pragma unroll
-    for (uint32_t d = 1; d <= 15; ++d) my_len += tid >= lane_value(cumv, d - 1) ? 1u : 0u;
-    if (q == 0 && lane <= 16) {
-        // cls[d] for d = 0 .. 16 (lane d takes the values of lane d - 1)
-        const uint32_t pc = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)((cumv << 17) | csv), 0x111,
-                                                                  0xF, 0xF, true);
-        L.cls[lane] = lane == 16 ? (256u << 17) | kraft : pc;
+        for (uint32_t d = 1; d <= 15; ++d) my_len += tid >= lane_value(cumv, d - 1) ? 1u : 0u;
+        if (tid < head) {
+            const uint32_t s = reinterpret_cast<const uint8_t*>(L.img + a0 + kHdr)[tid];
+            L.tab.r2s[tid] = (uint8_t)s;
+            __hip_atomic_fetch_or(&L.present[s >> 5], 1u << (s & 31u), __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     }
-    if (tid < head) {
-        const uint32_t s = reinterpret_cast<const uint8_t*>(L.img + a0 + kHdr)[tid];
-        L.r2s[tid] = (uint8_t)s;
-        __hip_atomic_fetch_or(&L.present[s >> 5], 1u << (s & 31u), __ATOMIC_RELAXED,
-                              __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    // region lengths and their prefix sum (wavefronts 0 and 1: one region per thread)
-    uint32_t R = 0, incl = 0;
+    // region lengths and their prefix sum (wavefronts 0 and 1: one region per thread; wavefront 1
+    // adds up wavefront 0's lengths itself)
+    uint32_t R = 0;
     if (q < 2) {
-        const uint32_t* gap = L.img + a0 + kHdr + hw;
-        const uint32_t bit = 12u * tid;
-        R = __builtin_amdgcn_alignbit(gap[(bit >> 5) + 1], gap[bit >> 5], bit & 31u) & 0xFFFu;
-        incl = wave_scan_incl(R);
-        if (q == 0 && lane == 63) L.red[0] = incl;
+        const uint32_t* gap = L.img + a0 + hdr0 + hw;
+        auto region = [&](const uint32_t r) {
+            const uint32_t bit = 12u * r;
+            return __builtin_amdgcn_alignbit(gap[(bit >> 5) + 1], gap[bit >> 5], bit & 31u) & 0xFFFu;
+        };
+        R = region(tid);
+        uint32_t incl = wave_scan_incl(R);
+        if (q == 1) incl += lane_value(wave_scan_incl(region((uint32_t)lane)), 63);
+        L.rstart[tid] = incl - R;
+        if (tid == 127) L.rstart[128] = incl;
     }
-    __syncthreads();
+    if (!SHARED) __syncthreads();  // (present[] complete)
 
-    {
+    if (!SHARED) {
         // The ranks behind the listed ones: the symbols not listed, ascending.  Symbol s = tid is
         // not listed <=> its bit of `present` is clear, and then its rank is head + s - (listed
         // symbols below s).  Lane i < 8 counts word i; a scan gives the counts below each word.
@@ -779,12 +976,7 @@ __global__ __launch_bounds__(256) void hf_k_decode_pages(
         const uint32_t mine = L.present[w];
         const uint32_t below = before + (lane >= 32 ? mid : 0u) +
                                (uint32_t)__popc(mine & ((1u << (tid & 31u)) - 1u));
-        if (!((mine >> (tid & 31u)) & 1u)) L.r2s[head + tid - below] = (uint8_t)tid;
-    }
-    if (q < 2) {
-        incl += q == 1 ? L.red[0] : 0u;
-        L.rstart[tid] = incl - R;
-        if (tid == 127) L.rstart[128] = incl;
+        if (!((mine >> (tid & 31u)) & 1u)) L.tab.r2s[head + tid - below] = (uint8_t)tid;
     }
     // the rest of the image
 #pragma unroll
@@ -796,37 +988,16 @@ __global__ __launch_bounds__(256) void hf_k_decode_pages(
 
     // ---- tables ----
     Tab T;
-    {
-        const uint32_t pc = L.cls[my_len - 1];
-        const uint32_t my_start = (pc & 0x1FFFFu) + ((tid - (pc >> 17)) << (16u - my_len));
-        const uint32_t val = ((uint32_t)L.r2s[tid] << 8) | my_len;
-        const uint32_t v2 = val | (val << 16);
-        // (a code's span starts at a multiple of its size: the widest aligned store that fits)
-        auto fill = [&](uint16_t* to, const uint32_t at, const uint32_t span) {
-            if (span >= 8) {
-                for (uint32_t i = 0; i < span; i += 8)
-                    *reinterpret_cast<uint4*>(to + at + i) = make_uint4(v2, v2, v2, v2);
-            } else if (span == 4) {
-                *reinterpret_cast<uint2*>(to + at) = make_uint2(v2, v2);
-            } else if (span == 2) {
-                *reinterpret_cast<uint32_t*>(to + at) = v2;
-            } else {
-                to[at] = (uint16_t)val;
-            }
-        };
-        const uint32_t tail_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)(L.cls[BITS] & 0x1FFFFu));
-        const uint32_t tail_span = kraft - tail_start;
-        T.tail_n = tail_span <= 512u ? tail_span : 0u;
-        T.tail_start = tail_start;
-        if (my_len <= (uint32_t)BITS)
-            fill(L.lut, my_start >> (16 - BITS), 1u << (BITS - my_len));
-        else if (T.tail_n != 0)
-            fill(L.tail, my_start - tail_start, 1u << (16u - my_len));
-        T.lut_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(L.lut));
-        T.tail_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(L.tail));
-        T.cls_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(L.cls));
-        T.r2s_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(L.r2s));
+    if (SHARED) {
+        T.tail_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.tab.tail_n);
+        T.tail_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.tab.tail_start);
+    } else {
+        fill_tables<BITS>(L.tab, tid, my_len, kraft, T.tail_n, T.tail_start);
     }
+    T.lut_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(L.tab.lut));
+    T.tail_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(L.tab.tail));
+    T.cls_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(L.tab.cls));
+    T.r2s_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(L.tab.r2s));
     const uint32_t r = (q & 1u) * 64u + (uint32_t)lane;
     const uint32_t s0 = L.rstart[r], s1 = L.rstart[r + 1];
     const bool sums = L.rstart[128] == B;
@@ -838,7 +1009,7 @@ __global__ __launch_bounds__(256) void hf_k_decode_pages(
     const uint8_t* side_chunk = side ? side + first : nullptr;
     const uint64_t out_first = page_ids ? (uint64_t)slot * HF_CHUNK_SYMS : first;
     void* out_chunk = reinterpret_cast<uint8_t*>(out) + out_first * elem_bytes;
-    const uint32_t hdr_words = kHdr + hw + kGap;
+    const uint32_t hdr_words = hdr0 + hw + kGap;
     uint32_t used;
     // (a full page's strings have 64 bits at least; a region shorter than two of them is damage,
     // and the whole wavefront then goes the careful way)
@@ -872,32 +1043,45 @@ __global__ __launch_bounds__(256) void hf_k_decode_pages(
 
 }  // namespace
 
-// sizes -> page offsets (d_page_off, nchunks + 1 values, the last one the total) -> pages
+// sizes -> page offsets (d_page_off, nchunks + 1 values, the last one the total) -> pages.
+// cbs: the per-page records; or, shared_cb given, null (pages without records, one codebook)
 void hf_launch_encode_pages(const void* d_data, uint64_t n, int layout, const hf_chunk_cb* cbs,
-                            const uint32_t* d_freq_chunks, uint8_t* d_side, uint32_t* d_payload,
-                            uint64_t cap_words, uint32_t* d_page_off,
+                            const hf_cb_dev* shared_cb, const uint32_t* d_freq_chunks, uint8_t* d_side,
+                            uint32_t* d_payload, uint64_t cap_words, uint32_t* d_page_off,
                             unsigned long long* d_scan_aux, uint32_t* d_err, hipStream_t s) {
     const uint64_t nchunks = (n + HF_CHUNK_SYMS - 1) / HF_CHUNK_SYMS;
     if (nchunks == 0) return;
     const uint64_t m = nchunks + 1;
-    hipLaunchKernelGGL(hf_k_page_sizes, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, s, d_freq_chunks,
-                       cbs, (uint32_t)nchunks, d_page_off);
+    if (shared_cb)
+        hipLaunchKernelGGL(hf_k_page_sizes_shared, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, s,
+                           d_freq_chunks, shared_cb, (uint32_t)nchunks, d_page_off);
+    else
+        hipLaunchKernelGGL(hf_k_page_sizes, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, s, d_freq_chunks,
+                           cbs, (uint32_t)nchunks, d_page_off);
     const u64 limit = cap_words < 0xFFFFFFFFull ? cap_words : 0xFFFFFFFFull;
     hf_launch_scan_u32(d_page_off, m, d_scan_aux, limit, d_err, s);
     const u64* d_total = d_scan_aux + (m + 1023) / 1024;
-    if (layout == HF_LAYOUT_BF16_EXP)
-        hipLaunchKernelGGL(hf_k_encode_pages<HF_LAYOUT_BF16_EXP>, dim3((unsigned)nchunks), dim3(256), 0,
-                           s, d_data, n, (uint32_t)nchunks, cbs, d_side, d_payload, d_page_off, d_total,
-                           limit, d_err);
-    else
-        hipLaunchKernelGGL(hf_k_encode_pages<HF_LAYOUT_U8>, dim3((unsigned)nchunks), dim3(256), 0, s,
-                           d_data, n, (uint32_t)nchunks, cbs, (uint8_t*)nullptr, d_payload, d_page_off,
-                           d_total, limit, d_err);
+    const void* cbp = shared_cb ? static_cast<const void*>(shared_cb) : static_cast<const void*>(cbs);
+    const bool wide = layout == HF_LAYOUT_BF16_EXP;
+#define HF_LAUNCH_ENC(LAY, SH)                                                                      \
+    hipLaunchKernelGGL((hf_k_encode_pages<LAY, SH>), dim3((unsigned)nchunks), dim3(256), 0, s, d_data, \
+                       n, (uint32_t)nchunks, cbp, wide ? d_side : (uint8_t*)nullptr, d_payload,        \
+                       d_page_off, d_total, limit, d_err)
+    if (wide && shared_cb) HF_LAUNCH_ENC(HF_LAYOUT_BF16_EXP, true);
+    else if (wide) HF_LAUNCH_ENC(HF_LAYOUT_BF16_EXP, false);
+    else if (shared_cb) HF_LAUNCH_ENC(HF_LAYOUT_U8, true);
+    else HF_LAUNCH_ENC(HF_LAYOUT_U8, false);
+#undef HF_LAUNCH_ENC
 }
 
+size_t hf_page_tab_image_bytes(void) { return sizeof(DecTabLds<11>); }
+
+// shared_cb given: pages without records; d_tab_image (hf_page_tab_image_bytes) receives the tables
+// of that codebook first
 void hf_launch_decode_pages(const uint32_t* d_payload, uint64_t payload_words,
                             const uint32_t* d_page_off, const uint8_t* d_side, uint64_t n,
-                            int layout, const uint32_t* d_page_ids, const uint32_t* d_out_slots,
+                            int layout, const hf_cb_dev* shared_cb, void* d_tab_image,
+                            const uint32_t* d_page_ids, const uint32_t* d_out_slots,
                             uint64_t n_slots, uint64_t n_ids, void* d_out, uint32_t* d_err,
                             hipStream_t s) {
     const uint64_t nchunks = (n + HF_CHUNK_SYMS - 1) / HF_CHUNK_SYMS;
@@ -905,22 +1089,18 @@ void hf_launch_decode_pages(const uint32_t* d_payload, uint64_t payload_words,
     if (n_work == 0) return;
     // (page offsets are 32-bit word indices: nothing behind 2^32 words is ever addressed)
     const uint32_t pw32 = payload_words > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)payload_words;
-    // (experiment switch: first-level width and where the escape test sits)
-    static const int variant = getenv("HF_PAGES_VARIANT") ? atoi(getenv("HF_PAGES_VARIANT")) : 0;
-#define HF_LAUNCH_DEC(LAY, BITS, PC, SIDE)                                                          \
-    hipLaunchKernelGGL((hf_k_decode_pages<LAY, BITS, PC>), dim3((unsigned)n_work), dim3(256), 0, s,  \
-                       d_payload, pw32, d_page_off, SIDE, n, (uint32_t)nchunks, d_page_ids,          \
-                       d_out_slots, (uint32_t)n_slots, d_out, d_err)
-    if (layout == HF_LAYOUT_BF16_EXP) {
-        HF_LAUNCH_DEC(HF_LAYOUT_BF16_EXP, 11, false, d_side);
-    } else if (variant == 1) {
-        HF_LAUNCH_DEC(HF_LAYOUT_U8, 11, true, (const uint8_t*)nullptr);
-    } else if (variant == 2) {
-        HF_LAUNCH_DEC(HF_LAYOUT_U8, 12, true, (const uint8_t*)nullptr);
-    } else if (variant == 3) {
-        HF_LAUNCH_DEC(HF_LAYOUT_U8, 12, false, (const uint8_t*)nullptr);
-    } else {
-        HF_LAUNCH_DEC(HF_LAYOUT_U8, 11, false, (const uint8_t*)nullptr);
-    }
+    DecTabLds<11>* const img = static_cast<DecTabLds<11>*>(d_tab_image);
+    if (shared_cb)
+        hipLaunchKernelGGL(hf_k_page_tab_image<11>, dim3(1), dim3(256), 0, s, shared_cb, img);
+    const bool wide = layout == HF_LAYOUT_BF16_EXP;
+#define HF_LAUNCH_DEC(LAY, SH)                                                                       \
+    hipLaunchKernelGGL((hf_k_decode_pages<LAY, 11, false, SH>), dim3((unsigned)n_work), dim3(256), 0, s, \
+                       d_payload, pw32, d_page_off, wide ? d_side : (const uint8_t*)nullptr, n,          \
+                       (uint32_t)nchunks, d_page_ids, d_out_slots, (uint32_t)n_slots, d_out,             \
+                       (const DecTabLds<11>*)img, d_err)
+    if (wide && shared_cb) HF_LAUNCH_DEC(HF_LAYOUT_BF16_EXP, true);
+    else if (wide) HF_LAUNCH_DEC(HF_LAYOUT_BF16_EXP, false);
+    else if (shared_cb) HF_LAUNCH_DEC(HF_LAYOUT_U8, true);
+    else HF_LAUNCH_DEC(HF_LAYOUT_U8, false);
 #undef HF_LAUNCH_DEC
 }

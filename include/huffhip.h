@@ -433,6 +433,28 @@ int hf_page_codebook_download(hf_ctx* ctx, const uint32_t* d_payload, uint64_t p
                               const uint32_t* d_page_off, uint64_t page, uint16_t* h_code,
                               uint8_t* h_len, int* mode, uint32_t* entropy_q16);
 
+/* Paged stream with ONE codebook for the whole stream (hf_system_codebook_dev on the stream's
+ * counts -- or on counts summed over GPUs, hf_symbol_stat_allreduce): the pages carry no record.
+ *   word 0   B << 10 | 1 << 29   (bit 29: "no record, the codes are the stream's"; bits 0..9 zero)
+ *   then     the 48 words of region lengths and the ceil(B / 32) words of strings, as above
+ * A page takes 49 + ceil(B / 32) words: no look-ahead words, no per-lane padding, 0.10 bits per
+ * symbol of page overhead.  d_freq_chunks are the per-page counts (hf_symbol_stat_chunks_dev;
+ * hf_symbol_stat_fold_dev sums them into the stream's 256 counts, so the data is read once for
+ * both); d_codebook must be a canonical codebook, which every codebook this library builds is
+ * (an uploaded table of another shape makes every page report HF_ERR_CORRUPT).  The decoder copies
+ * tables made once per call from the codebook instead of building them per page.  Everything
+ * else as hf_encode_pages / hf_decode_pages; hf_pages_bound_words bounds these pages too.  In a
+ * container: HF_PLACEMENT_PAGED with HF_CODEBOOK_STREAM. */
+int hf_encode_pages_shared(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
+                           const void* d_codebook, const uint32_t* d_freq_chunks, uint8_t* d_side,
+                           uint32_t* d_payload, uint64_t payload_cap_words, uint32_t* d_page_off,
+                           uint64_t* h_total_words);
+int hf_decode_pages_shared(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
+                           const uint32_t* d_page_off, const uint8_t* d_side, uint64_t n, int layout,
+                           const void* d_codebook, const uint32_t* d_page_ids,
+                           const uint32_t* d_out_slots, uint64_t n_ids, void* d_out,
+                           uint64_t n_slots, int check);
+
 /* bulk read of one record: code/length by symbol, mode, entropy (synchronises) */
 int hf_chunk_codebook_download(hf_ctx* ctx, const void* d_chunk_codebooks, uint64_t chunk,
                                uint16_t* h_code, uint8_t* h_len, int* mode, uint32_t* entropy_q16);
@@ -457,7 +479,8 @@ int hf_chunk_codebook_download(hf_ctx* ctx, const void* d_chunk_codebooks, uint6
  *                rank2sym u8[256] (symbols in (count desc, symbol asc) order), u16[16] number of
  *                ranks with code length 1..16 (lengths never decrease with rank, codes are
  *                canonical in rank order), u32 mode, u32 entropy_q16;
- *                absent (off_codebook = 0) for HF_PLACEMENT_PAGED: the records are in the pages
+ *                absent (off_codebook = 0) for HF_PLACEMENT_PAGED with HF_CODEBOOK_PER_CHUNK:
+ *                the records are in the pages
  *     chunk_off  u32[nchunks + 1]: first words of the chunks / slots / pages, then the total
  *     chunk_words  HF_PLACEMENT_SLOTTED only: u32[nchunks], the words each chunk fills of its slot
  *     side       HF_LAYOUT_BF16_EXP: u8[n]; HF_LAYOUT_FP16_EXP, _FP8_E4M3_EXP, _FP4_E2M1_EXP: the packed
@@ -473,7 +496,8 @@ int hf_chunk_codebook_download(hf_ctx* ctx, const void* d_chunk_codebooks, uint6
 #define HF_CODEBOOK_PER_CHUNK 1
 #define HF_PLACEMENT_DENSE 0   /* chunks back to back (hf_encode, hf_encode_chunks)          */
 #define HF_PLACEMENT_SLOTTED 1 /* chunks in slots, with chunk_words                          */
-#define HF_PLACEMENT_PAGED 2   /* self-contained pages (hf_encode_pages), HF_CODEBOOK_PER_CHUNK */
+#define HF_PLACEMENT_PAGED 2   /* pages: with their records (hf_encode_pages, HF_CODEBOOK_PER_CHUNK)
+                                  or without (hf_encode_pages_shared, HF_CODEBOOK_STREAM) */
 
 typedef struct hf_container_info {
     uint32_t version;

@@ -917,25 +917,9 @@ static size_t page_symbol(unsigned q, unsigned l, unsigned rr, unsigned j) {
     return (((size_t)(q * PAGE_SUB_ROUNDS + rr)) * ORC_LANES + l) * ORC_GROUP + j;
 }
 
-/* One page from its symbols and its codebook (code / len by symbol; rank2sym / len_by_rank in
- * rank order).  Returns the page's words; out may be NULL to size only. */
-uint64_t orc_rp_encode_page(const uint8_t* sym, size_t m, const uint16_t* code, const uint8_t* len,
-                            const uint8_t* rank2sym, const uint8_t* len_by_rank, uint32_t mode,
-                            uint32_t entropy_q16, uint32_t* out) {
-    uint64_t B = 0;
-    for (size_t i = 0; i < m; ++i) B += len[sym[i]];
-    const uint32_t head = orc_rp_page_head(rank2sym);
-    const uint64_t words = orc_rp_page_words(head, B);
-    if (!out) return words;
-    memset(out, 0, (size_t)words * 4u);
-    out[0] = head | ((mode & 1u) << 9) | ((uint32_t)B << 10);
-    out[1] = entropy_q16;
-    for (int p = 0; p < 256; ++p) {
-        const unsigned L = len_by_rank[p];
-        if (L >= 1 && L <= 16) out[2 + (L - 1) / 2] += 1u << (16u * ((L - 1) & 1u));
-    }
-    for (uint32_t p = 0; p < head; ++p) out[PAGE_HDR_WORDS + p / 4] |= (uint32_t)rank2sym[p] << (8u * (p & 3u));
-    uint32_t* gap = out + PAGE_HDR_WORDS + (head + 3u) / 4u;
+/* region lengths (48 words at gap) and strings (behind them) of one page, into zeroed memory */
+static void page_strings(const uint8_t* sym, size_t m, const uint16_t* code, const uint8_t* len,
+                         uint32_t* gap) {
     uint32_t* str = gap + PAGE_GAP_WORDS;
     uint64_t at = 0;
     for (unsigned r = 0; r < 128; ++r) {
@@ -967,6 +951,27 @@ uint64_t orc_rp_encode_page(const uint8_t* sym, size_t m, const uint16_t* code, 
             if ((R >> b) & 1u) gap[(12u * r + b) >> 5] |= 1u << ((12u * r + b) & 31u);
         at += R;
     }
+}
+
+/* One page from its symbols and its codebook (code / len by symbol; rank2sym / len_by_rank in
+ * rank order).  Returns the page's words; out may be NULL to size only. */
+uint64_t orc_rp_encode_page(const uint8_t* sym, size_t m, const uint16_t* code, const uint8_t* len,
+                            const uint8_t* rank2sym, const uint8_t* len_by_rank, uint32_t mode,
+                            uint32_t entropy_q16, uint32_t* out) {
+    uint64_t B = 0;
+    for (size_t i = 0; i < m; ++i) B += len[sym[i]];
+    const uint32_t head = orc_rp_page_head(rank2sym);
+    const uint64_t words = orc_rp_page_words(head, B);
+    if (!out) return words;
+    memset(out, 0, (size_t)words * 4u);
+    out[0] = head | ((mode & 1u) << 9) | ((uint32_t)B << 10);
+    out[1] = entropy_q16;
+    for (int p = 0; p < 256; ++p) {
+        const unsigned L = len_by_rank[p];
+        if (L >= 1 && L <= 16) out[2 + (L - 1) / 2] += 1u << (16u * ((L - 1) & 1u));
+    }
+    for (uint32_t p = 0; p < head; ++p) out[PAGE_HDR_WORDS + p / 4] |= (uint32_t)rank2sym[p] << (8u * (p & 3u));
+    page_strings(sym, m, code, len, out + PAGE_HDR_WORDS + (head + 3u) / 4u);
     return words;
 }
 
@@ -1053,6 +1058,58 @@ int orc_rp_page_codebook(const uint32_t* page, uint64_t words, uint16_t* code, u
     return 0;
 }
 
+/* direct table over the left-aligned 16-bit code space: length << 8 | symbol, 0 = no code */
+static void page_code_table(const uint16_t* code, const uint8_t* len, uint16_t* tab) {
+    memset(tab, 0, 65536 * sizeof(uint16_t));
+    for (int s = 0; s < 256; ++s) {
+        const unsigned L = len[s];
+        if (L < 1 || L > 16) continue;
+        const unsigned first = (unsigned)code[s] << (16 - L);
+        for (unsigned e = 0; e < (1u << (16 - L)); ++e) tab[first + e] = (uint16_t)((L << 8) | s);
+    }
+}
+
+/* the strings of one page of m symbols back into symbols; 0, or -1 when they do not decode */
+static int page_decode_strings(const uint32_t* gap, uint32_t B, size_t m, const uint16_t* tab,
+                               uint8_t* sym_out) {
+    const uint32_t* str = gap + PAGE_GAP_WORDS;
+    int rc = 0;
+    uint64_t at = 0;
+    for (unsigned r = 0; r < 128 && rc == 0; ++r) {
+        unsigned R = 0;
+        for (unsigned b = 0; b < 12; ++b) R |= ((gap[(12u * r + b) >> 5] >> ((12u * r + b) & 31u)) & 1u) << b;
+        if (at + R > B) return -1;
+        unsigned used[2] = {0, 0};
+        for (unsigned dir = 0; dir < 2 && rc == 0; ++dir) {
+            const unsigned q = (r >> 6) + 2 * dir, l = r & 63u;
+            unsigned k = 0;
+            for (unsigned rr = 0; rr < PAGE_SUB_ROUNDS && rc == 0; ++rr)
+                for (unsigned j = 0; j < ORC_GROUP; ++j) {
+                    const size_t i = page_symbol(q, l, rr, j);
+                    if (i >= m) continue;
+                    /* the next 16 bits of the string, zeros past the region */
+                    const unsigned nb = R - k < 16 ? R - k : 16;
+                    unsigned v = dir ? bit_reverse(get_bits(str, at + R - k - nb, nb), nb)
+                                     : get_bits(str, at + k, nb);
+                    v <<= 16 - nb;
+                    const uint16_t e = tab[v];
+                    const unsigned L = e >> 8;
+                    if (L == 0 || k + L > R) {
+                        rc = -1;
+                        break;
+                    }
+                    sym_out[i] = (uint8_t)(e & 0xFF);
+                    k += L;
+                }
+            used[dir] = k;
+        }
+        if (rc == 0 && used[0] + used[1] != R) rc = -1;
+        at += R;
+    }
+    if (rc == 0 && at != B) rc = -1;
+    return rc;
+}
+
 /* Returns 0, or -1 if a page does not decode (bad record, region lengths that do not add up to B,
  * no matching code, a region whose two strings do not meet exactly). */
 int orc_rp_decode_pages(const uint32_t* payload, const uint32_t* page_off, size_t n,
@@ -1071,51 +1128,64 @@ int orc_rp_decode_pages(const uint32_t* payload, const uint32_t* page_off, size_
             rc = -1;
             break;
         }
-        memset(tab, 0, 65536 * sizeof(uint16_t));
-        for (int s = 0; s < 256; ++s) {
-            const unsigned L = len[s];
-            const unsigned first = (unsigned)code[s] << (16 - L);
-            for (unsigned e = 0; e < (1u << (16 - L)); ++e) tab[first + e] = (uint16_t)((L << 8) | s);
-        }
+        page_code_table(code, len, tab);
         const uint32_t head = page[0] & 0x1FFu, B = page[0] >> 10;
-        const uint32_t* gap = page + PAGE_HDR_WORDS + (head + 3u) / 4u;
-        const uint32_t* str = gap + PAGE_GAP_WORDS;
-        uint64_t at = 0;
-        for (unsigned r = 0; r < 128 && rc == 0; ++r) {
-            unsigned R = 0;
-            for (unsigned b = 0; b < 12; ++b) R |= ((gap[(12u * r + b) >> 5] >> ((12u * r + b) & 31u)) & 1u) << b;
-            if (at + R > B) {
-                rc = -1;
-                break;
-            }
-            unsigned used[2] = {0, 0};
-            for (unsigned dir = 0; dir < 2 && rc == 0; ++dir) {
-                const unsigned q = (r >> 6) + 2 * dir, l = r & 63u;
-                unsigned k = 0;
-                for (unsigned rr = 0; rr < PAGE_SUB_ROUNDS && rc == 0; ++rr)
-                    for (unsigned j = 0; j < ORC_GROUP; ++j) {
-                        const size_t i = page_symbol(q, l, rr, j);
-                        if (i >= m) continue;
-                        /* the next 16 bits of the string, zeros past the region */
-                        const unsigned nb = R - k < 16 ? R - k : 16;
-                        unsigned v = dir ? bit_reverse(get_bits(str, at + R - k - nb, nb), nb)
-                                         : get_bits(str, at + k, nb);
-                        v <<= 16 - nb;
-                        const uint16_t e = tab[v];
-                        const unsigned L = e >> 8;
-                        if (L == 0 || k + L > R) {
-                            rc = -1;
-                            break;
-                        }
-                        sym_out[base + i] = (uint8_t)(e & 0xFF);
-                        k += L;
-                    }
-                used[dir] = k;
-            }
-            if (rc == 0 && used[0] + used[1] != R) rc = -1;
-            at += R;
+        rc = page_decode_strings(page + PAGE_HDR_WORDS + (head + 3u) / 4u, B, m, tab, sym_out + base);
+    }
+    free(tab);
+    return rc;
+}
+
+/* ---- paged stream with one codebook for the whole stream ("shared" pages) ---------------------
+ * The same pages without a record: word 0 = B << 10 | 1 << 29 (bit 29 says "no record: the codes
+ * are the stream's"), then the 48 words of region lengths, then the strings -- a page takes
+ * 49 + ceil(B / 32) words.  The codebook travels beside the stream (container codebook section).
+ * PARITY UNPINNED, as orc_rp_encode. */
+#define PAGE_SHARED_FLAG (1u << 29)
+
+uint64_t orc_rp_shared_page_words(uint64_t bits) { return 1u + PAGE_GAP_WORDS + (bits + 31u) / 32u; }
+
+uint64_t orc_rp_encode_pages_shared(const uint8_t* sym, size_t n, const uint16_t* code,
+                                    const uint8_t* len, uint32_t* payload, uint32_t* page_off) {
+    const size_t nchunks = orc_num_chunks(n);
+    uint64_t pos = 0;
+    for (size_t c = 0; c < nchunks; ++c) {
+        const size_t base = c * (size_t)ORC_CHUNK_SYMS;
+        const size_t m = n - base < ORC_CHUNK_SYMS ? n - base : ORC_CHUNK_SYMS;
+        uint64_t B = 0;
+        for (size_t i = 0; i < m; ++i) B += len[sym[base + i]];
+        const uint64_t words = orc_rp_shared_page_words(B);
+        if (page_off) page_off[c] = (uint32_t)pos;
+        if (payload) {
+            uint32_t* out = payload + pos;
+            memset(out, 0, (size_t)words * 4u);
+            out[0] = ((uint32_t)B << 10) | PAGE_SHARED_FLAG;
+            page_strings(sym + base, m, code, len, out + 1);
         }
-        if (rc == 0 && at != B) rc = -1;
+        pos += words;
+    }
+    if (page_off) page_off[nchunks] = (uint32_t)pos;
+    return pos;
+}
+
+int orc_rp_decode_pages_shared(const uint32_t* payload, const uint32_t* page_off, size_t n,
+                               const uint16_t* code, const uint8_t* len, uint8_t* sym_out) {
+    const size_t nchunks = orc_num_chunks(n);
+    uint16_t* tab = (uint16_t*)malloc(65536 * sizeof(uint16_t));
+    int rc = 0;
+    page_code_table(code, len, tab);
+    for (size_t c = 0; c < nchunks && rc == 0; ++c) {
+        const size_t base = c * (size_t)ORC_CHUNK_SYMS;
+        const size_t m = n - base < ORC_CHUNK_SYMS ? n - base : ORC_CHUNK_SYMS;
+        const uint32_t* page = payload + page_off[c];
+        const uint64_t words = (uint64_t)page_off[c + 1] - page_off[c];
+        const uint32_t B = (page[0] >> 10) & 0x7FFFFu;
+        if (page_off[c + 1] < page_off[c] || words < 1u + PAGE_GAP_WORDS ||
+            (page[0] & 0x3FFu) != 0 || (page[0] >> 29) != 1u || orc_rp_shared_page_words(B) != words) {
+            rc = -1;
+            break;
+        }
+        rc = page_decode_strings(page + 1, B, m, tab, sym_out + base);
     }
     free(tab);
     return rc;
@@ -1124,15 +1194,15 @@ int orc_rp_decode_pages(const uint32_t* payload, const uint32_t* page_off, size_
 /* ---- container, wire format version 2 ------------------------------------------------------
  * Version 1 plus a placement field and, for slotted streams, the words array: header bytes 104
  * (u32 placement: 1 slotted, 2 paged), 108 (zero), 112 (u64 offset of the words array, 0 unless
- * slotted).  Sections: codebook (as version 1; absent, offset 0, for a paged stream, whose pages
- * carry the records), chunk offsets, chunk words (slotted only, u32[nchunks]), side bytes,
+ * slotted).  Sections: codebook (as version 1; absent, offset 0, for a paged stream of codebook
+ * kind 1, whose pages carry the records), chunk offsets, chunk words (slotted only, u32[nchunks]), side bytes,
  * payload.  A dense stream (placement 0) is always a version-1 container. */
 static void container2_offsets(uint64_t n, int layout, int kind, int placement, uint64_t payload_words,
                                uint64_t off[5], uint64_t* total) {
     const uint64_t nchunks = orc_num_chunks((size_t)n);
     uint64_t at = 128;
     off[0] = 0;
-    if (placement != 2) {
+    if (placement != 2 || kind == 0) { /* (shared pages: the stream's one codebook) */
         off[0] = at;
         at = round16(at + (kind == 0 ? 768u : nchunks * 296u));
     }

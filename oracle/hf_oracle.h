@@ -210,6 +210,12 @@ int orc_rp_page_codebook(const uint32_t* page, uint64_t words, uint16_t* code, u
                          uint32_t* mode, uint32_t* entropy_q16);
 int orc_rp_decode_pages(const uint32_t* payload, const uint32_t* page_off, size_t n,
                         uint8_t* sym_out);
+/* paged stream with one codebook for the stream: pages without a record (word 0 = B << 10 | 1 << 29) */
+uint64_t orc_rp_shared_page_words(uint64_t bits);
+uint64_t orc_rp_encode_pages_shared(const uint8_t* sym, size_t n, const uint16_t* code,
+                                    const uint8_t* len, uint32_t* payload, uint32_t* page_off);
+int orc_rp_decode_pages_shared(const uint32_t* payload, const uint32_t* page_off, size_t n,
+                               const uint16_t* code, const uint8_t* len, uint8_t* sym_out);
 
 size_t orc_num_chunks(size_t n);
 /* Upper bound on payload words for n symbols under any codebook with lengths <= 16. */

@@ -116,6 +116,12 @@ def _declare(l: C.CDLL) -> None:
     l.orc_rp_page_codebook.restype = C.c_int
     l.orc_rp_decode_pages.argtypes = [_u32p, _u32p, C.c_size_t, _u8p]
     l.orc_rp_decode_pages.restype = C.c_int
+    l.orc_rp_shared_page_words.argtypes = [C.c_uint64]
+    l.orc_rp_shared_page_words.restype = C.c_uint64
+    l.orc_rp_encode_pages_shared.argtypes = [_u8p, C.c_size_t, _u16p, _u8p, _u32p, _u32p]
+    l.orc_rp_encode_pages_shared.restype = C.c_uint64
+    l.orc_rp_decode_pages_shared.argtypes = [_u32p, _u32p, C.c_size_t, _u16p, _u8p, _u8p]
+    l.orc_rp_decode_pages_shared.restype = C.c_int
     l.orc_num_chunks.argtypes = [C.c_size_t]
     l.orc_num_chunks.restype = C.c_size_t
     l.orc_payload_bound_words.argtypes = [C.c_size_t]
@@ -342,7 +348,8 @@ def container_pack(n, layout, payload, chunk_off, side=None, code=None, lens=Non
                    placement=0, chunk_words=None):
     """The container as bytes.  One codebook (code, lens, mode, entropy_q16) or per-chunk canonical
     orders (rank2sym, len_by_rank: nchunks x 256; modes, entropies).  placement 0: dense, wire
-    format version 1; 1: slotted (with chunk_words); 2: paged (no codebook section) -- version 2."""
+    format version 1; 1: slotted (with chunk_words); 2: paged (no codebook section, or the one codebook of pages
+    without records when code / lens are given) -- version 2."""
     l = lib()
     l.orc_container2_bytes.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_uint64]
     l.orc_container2_bytes.restype = C.c_uint64
@@ -350,7 +357,7 @@ def container_pack(n, layout, payload, chunk_off, side=None, code=None, lens=Non
                                       C.c_uint32, C.c_uint32, _u16p, _u8p, _u8p, _u8p, _u32p, _u32p,
                                       _u32p, _u32p, _u8p, _u32p]
     l.orc_container2_pack.restype = C.c_uint64
-    kind = 1 if (rank2sym is not None or placement == 2) else 0
+    kind = 1 if (rank2sym is not None or (placement == 2 and code is None)) else 0
     payload = _arr(payload, np.uint32)
     chunk_off = _arr(chunk_off, np.uint32)
     total = int(l.orc_container2_bytes(n, layout, kind, placement, payload.size))
@@ -540,6 +547,40 @@ def rp_page_codebook(payload, page_off, page: int):
     rc = lib().orc_rp_page_codebook(_p(pg, _u32p), max(b - a, 0), _p(code, _u16p), _p(lens, _u8p),
                                     C.byref(mode), C.byref(ent))
     return None if rc else (code, lens, int(mode.value), int(ent.value))
+
+
+def shared_page_words(bits: int) -> int:
+    return int(lib().orc_rp_shared_page_words(bits))
+
+
+def rp_encode_pages_shared(sym, code, lens):
+    """Pages without records, all coded with one codebook: (payload u32, page_off u32[nchunks+1])."""
+    sym = _arr(sym, np.uint8)
+    code = _arr(code, np.uint16)
+    lens = _arr(lens, np.uint8)
+    nch = num_chunks(sym.size)
+    off = np.zeros(nch + 1, np.uint32)
+    total = int(lib().orc_rp_encode_pages_shared(_p(sym, _u8p), sym.size, _p(code, _u16p),
+                                                 _p(lens, _u8p), None, _p(off, _u32p)))
+    payload = np.zeros(max(total, 1), np.uint32)
+    lib().orc_rp_encode_pages_shared(_p(sym, _u8p), sym.size, _p(code, _u16p), _p(lens, _u8p),
+                                     _p(payload, _u32p), _p(off, _u32p))
+    return payload[:total], off
+
+
+def rp_decode_pages_shared(payload, page_off, n: int, code, lens) -> np.ndarray:
+    payload = _arr(payload, np.uint32)
+    if payload.size == 0:
+        payload = np.zeros(1, np.uint32)
+    page_off = _arr(page_off, np.uint32)
+    code = _arr(code, np.uint16)
+    lens = _arr(lens, np.uint8)
+    out = np.zeros(max(n, 1), np.uint8)
+    rc = lib().orc_rp_decode_pages_shared(_p(payload, _u32p), _p(page_off, _u32p), n,
+                                          _p(code, _u16p), _p(lens, _u8p), _p(out, _u8p))
+    if rc != 0:
+        raise ValueError("pages do not decode")
+    return out[:n]
 
 
 def rp_decode_pages(payload, page_off, n: int) -> np.ndarray:

@@ -61,7 +61,8 @@ def test_oracle_container_fields(orc):
 
 
 def test_placed_plan_matches_oracle_sizes(lib, orc):
-    """Wire format version 2 (slotted: a words array; paged: no codebook section)."""
+    """Wire format version 2 (slotted: a words array; paged: no codebook section when the pages
+    carry records, the stream's one codebook when they do not)."""
     from huffman_amd import _lib as L
     ol = orc.lib()
     ol.orc_container2_bytes.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_uint64]
@@ -69,19 +70,18 @@ def test_placed_plan_matches_oracle_sizes(lib, orc):
     info = L.hf_container_info()
     for n in (0, 1, 16384, 16385, 10**6 + 7):
         for layout in (0, 1):
-            for kind, placement in ((0, 0), (1, 0), (0, 1), (1, 1), (1, 2)):
+            for kind, placement in ((0, 0), (1, 0), (0, 1), (1, 1), (1, 2), (0, 2)):
                 for words in (0, 3, 4, 12345):
                     assert lib.hf_container_plan_placed(n, layout, kind, placement, words,
                                                         C.byref(info)) == 0
                     assert info.total_bytes == ol.orc_container2_bytes(n, layout, kind, placement, words)
                     assert info.version == (1 if placement == 0 else 2)
                     assert (info.off_chunk_words != 0) == (placement == 1)
-                    assert (info.off_codebook == 0) == (placement == 2)
+                    assert (info.off_codebook == 0) == (placement == 2 and kind == 1)
                     for off in (info.off_codebook, info.off_chunk_off, info.off_chunk_words,
                                 info.off_side, info.off_payload, info.total_bytes):
                         assert off % 16 == 0
-    # a paged stream always has per-page records; unknown placements are refused
-    assert lib.hf_container_plan_placed(10, 0, 0, 2, 1, C.byref(info)) == L.HF_ERR_ARG
+    # unknown placements are refused
     assert lib.hf_container_plan_placed(10, 0, 1, 3, 1, C.byref(info)) == L.HF_ERR_ARG
 
 
