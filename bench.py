@@ -3,8 +3,12 @@
 Gaussian bf16 weight stream on MI355X.
 
 One step = one pass of the hot path over the whole tensor, inputs resident in HBM:
-    SymbolStat (histogram) -> [all-reduce of the 256 counts when N > 1: global codebook]
-    -> sort/entropy/tree/adjust/canonical codes -> encode -> decode.
+    SymbolStat per 16384-element page, folded into the tensor's 256 counts
+    -> [all-reduce of the 256 counts when N > 1: global codebook]
+    -> sort/entropy/tree/adjust/canonical codes -> encode -> decode,
+the stored form being the paged stream with one codebook (pages without records, sized exactly
+from their counts; hf_encode_pages_shared / hf_decode_pages_shared).  The packed stream of format
+version 1 (hf_encode / hf_decode) is timed beside it, outside the timed region, as `dense_v1`.
 `value` = uncompressed bytes through that round trip per second, summed over all ranks.
 Run as `python bench.py --gpus N`: for N > 1 the script starts one rank per GPU itself (through
 torch.distributed.run, before anything touches a GPU) unless it already runs under such a
@@ -65,9 +69,9 @@ def cpu_baseline(torch, w_gpu, sample_elems):
     freq = orc.aw_symbol_stat(sym, 256, 64)
     code, lens = orc.rp_system_codebook(freq, 64, 0, 16)
     t1 = time.perf_counter()
-    payload, off = orc.rp_encode(sym, code, lens)  # sizes, then packs: two passes
+    payload, off = orc.rp_encode_pages_shared(sym, code, lens)  # sizes, then packs: two passes
     t2 = time.perf_counter()
-    out = orc.rp_decode(payload, off, m, code, lens)
+    out = orc.rp_decode_pages_shared(payload, off, m, code, lens)
     back = orc.desymbolize(out, side, orc.LAYOUT_BF16_EXP)
     t3 = time.perf_counter()
     assert np.array_equal(back, w)
@@ -97,8 +101,8 @@ def cpu_baseline(torch, w_gpu, sample_elems):
 
     def back_half(args):
         (s, sd, _), b = args
-        p, o = orc.rp_encode(s, code2, lens2)
-        d = orc.rp_decode(p, o, s.size, code2, lens2)
+        p, o = orc.rp_encode_pages_shared(s, code2, lens2)
+        d = orc.rp_decode_pages_shared(p, o, s.size, code2, lens2)
         return bool(np.array_equal(orc.desymbolize(d, sd, orc.LAYOUT_BF16_EXP), w[b[0]:b[1]]))
 
     with ThreadPoolExecutor(threads) as ex:
@@ -135,8 +139,8 @@ def pmc_traffic(n, lib_hash):
         if d.get("elements_per_gpu") != n or d.get("library_sha256_16") != lib_hash:
             continue
         out = {}
-        for phase, kern in (("hist", "hf_k_hist"), ("encode", "hf_k_encode"),
-                            ("decode", "hf_k_decode")):
+        for phase, kern in (("hist", "hf_k_hist_chunks"), ("encode", "hf_k_encode_pages"),
+                            ("decode", "hf_k_decode_pages")):
             k = d.get(kern, {})
             if "FETCH_SIZE_KiB_per_launch" in k and "WRITE_SIZE_KiB_per_launch" in k:
                 out[phase] = (2.0 * k["FETCH_SIZE_KiB_per_launch"]
@@ -248,7 +252,9 @@ def main():
     stat = hf.SymbolStat(ctx=ctx)
 
     nch = (n + hf.HF_CHUNK_SYMS - 1) // hf.HF_CHUNK_SYMS
+    ctx.reserve(n)
     freq = torch.zeros(256, dtype=torch.int64, device=device)
+    freq_pages = torch.empty(nch * 256, dtype=torch.int32, device=device)
     cb = hf.DeviceCodebook(ctx)
     side = torch.empty(n, dtype=torch.uint8, device=device)
     payload = torch.empty(n // 8 + nch * 192 + 64, dtype=torch.int32, device=device)  # 4 bits/sym
@@ -258,13 +264,14 @@ def main():
     def step(ev=None):
         if ev: ev[0].record()
         freq.zero_()
-        stat.accumulate(w, freq)
+        system.histogram_pages(w, freq_chunks=freq_pages, freq256=freq)
         if ev: ev[1].record()
         if use_dist:
             allreduce_counts(freq)  # global codebook: identical tables on every rank
         system.codebook(freq, hf.HF_MODE_HUFFMAN, out=cb)
         if ev: ev[2].record()
-        s = system.encode_with(w, cb, payload=payload, side=side, chunk_off=chunk_off, sync=False)
+        s = system.encode_with(w, cb, payload=payload, side=side, chunk_off=chunk_off, sync=False,
+                               paged=True, chunk_freq=freq_pages)
         if ev: ev[3].record()
         decoder.decode(s, out=out, check_stream=False)
         if ev: ev[4].record()
@@ -309,6 +316,44 @@ def main():
     nsym_codebook = float(f.sum())  # n * world when the histogram was all-reduced
     lbar = bits_ideal / max(1.0, nsym_codebook)
     comp_bytes = 4 * total_words + n + 4 * (nch + 1) + 256 * 3
+    stream_ok = True
+    if rank == 0:
+        # the GPU's pages against the oracle's, on the first pages of the tensor
+        import numpy as np
+        from oracle import oracle as orc
+        orc.build()
+        m = min(n, 64 * hf.HF_CHUNK_SYMS)
+        sym, _ = orc.symbolize(w[:m].view(torch.int16).cpu().numpy().view(np.uint16),
+                               orc.LAYOUT_BF16_EXP)
+        ref_payload, ref_off = orc.rp_encode_pages_shared(sym, code, lens)
+        got = payload[:ref_payload.size].cpu().numpy().view(np.uint32)
+        stream_ok = bool(np.array_equal(got, ref_payload)) and bool(np.array_equal(
+            chunk_off[:ref_off.size].cpu().numpy().view(np.uint32), ref_off))
+
+    # the packed stream of format version 1 on the same tensor and codebook, outside the timed
+    # region: histogram in one piece, look-back encoder, one wavefront per chunk in the decoder
+    dense = None
+    if rank == 0:
+        dev_ms = []
+        for _ in range(3):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            e[0].record()
+            freq.zero_()
+            stat.accumulate(w, freq)
+            e[1].record()
+            sd = system.encode_with(w, cb, payload=payload, side=side, chunk_off=chunk_off, sync=False)
+            e[2].record()
+            decoder.decode(sd, out=out, check_stream=False)
+            e[3].record()
+            torch.cuda.synchronize()
+            dev_ms.append([e[i].elapsed_time(e[i + 1]) for i in range(3)])
+        ctx.sync()
+        med = [sorted(x[i] for x in dev_ms)[1] for i in range(3)]
+        dwords = int(chunk_off[nch].item()) & 0xFFFFFFFF
+        dense = {"hist_ms": med[0], "encode_ms": med[1], "decode_ms": med[2],
+                 "bits_per_exponent_stream": 32.0 * dwords / n,
+                 "compression_ratio": 2.0 * n / (4 * dwords + n + 4 * (nch + 1) + 256 * 3),
+                 "roundtrip_bit_exact": bool(torch.equal(out.view(torch.int16), w.view(torch.int16)))}
     # TreeQualityAnalyzer (tree_q_analyser.scala:21-47) on this codebook.  Its weighted sum is a
     # 32-bit wire, so the counts go in shifted right until sum(count x length) fits.
     fi = freq.cpu().numpy().astype("uint64")
@@ -324,6 +369,8 @@ def main():
     ratio = 2.0 * n / comp_bytes
 
     raw_bytes = 2.0 * n
+    # algorithmic bytes per launch: elements, side bytes, the codes at their ideal size (the page
+    # headers, region lengths and per-page counts the kernels also move are not counted)
     alg = {
         "hist": 2.0 * n,
         "encode": n * (2.0 + 1.0 + lbar / 8.0) + 4.0 * nch,
@@ -352,7 +399,8 @@ def main():
             "config": {
                 "workload": ("synthetic Gaussian bf16 weights N(0,0.02^2), "
                              f"{n} elements per GPU ({raw_bytes / 1e9:.2f} GB), exponent-byte "
-                             "Huffman, forced Huffman mode, Lmax=16, 16384-symbol chunks"
+                             "Huffman, forced Huffman mode, Lmax=16, one codebook, paged stream "
+                             "of 16384-symbol pages without records"
                              + (", global codebook via RCCL all-reduce of the histogram"
                                 if world > 1 and backend == "nccl" else "")
                              + (", REHEARSAL: ranks share GPUs, counts summed over gloo"
@@ -371,6 +419,8 @@ def main():
             "compression_mode": mode, "entropy_q16": ent,
             "tree_quality": quality,
             "roundtrip_bit_exact": ok,
+            "pages_equal_oracle_on_sample": stream_ok,
+            "dense_v1": dense,
             "library_sha256_16": lib_hash,
             "roofline": dict(roof[dominant], kernel=dominant),
             "roofline_all": roof,
@@ -381,8 +431,8 @@ def main():
     if use_dist:
         barrier()
         dist.destroy_process_group()
-    if not ok:
-        raise SystemExit("round trip mismatch")
+    if not ok or not stream_ok:
+        raise SystemExit("round trip mismatch" if not ok else "pages differ from the oracle's")
 
 
 if __name__ == "__main__":

@@ -543,6 +543,30 @@ class EntropyAwareHuffmanSystem(_Module):
         SymbolStat(ctx=self.ctx).accumulate(data_in, freq256, layout)
         return freq256
 
+    @_on_ctx_stream
+    def histogram_pages(self, data_in: torch.Tensor, layout: Optional[int] = None,
+                        freq_chunks: Optional[torch.Tensor] = None,
+                        freq256: Optional[torch.Tensor] = None):
+        """SymbolStat per 16384-symbol page (``hf_symbol_stat_chunks_dev``) and, folded from those
+        (``hf_symbol_stat_fold_dev``), of the whole stream: the data is read once for both.
+        Returns (int32[nchunks * 256], int64[256]); ``freq256`` given is added into."""
+        lay = layout_of(data_in) if layout is None else layout
+        data_in = data_in.contiguous()
+        n = data_in.numel()
+        nch = (n + HF_CHUNK_SYMS - 1) // HF_CHUNK_SYMS
+        if freq_chunks is None:
+            freq_chunks = torch.empty(max(1, nch) * 256, dtype=torch.int32, device=data_in.device)
+        if freq256 is None:
+            freq256 = torch.zeros(256, dtype=torch.int64, device=data_in.device)
+        h = self.ctx.handle
+        check(L.lib().hf_symbol_stat_chunks_dev(h, C.c_void_p(_dev_ptr(data_in)), n, lay,
+                                                C.c_void_p(freq_chunks.data_ptr())),
+              "hf_symbol_stat_chunks_dev")
+        check(L.lib().hf_symbol_stat_fold_dev(h, C.c_void_p(freq_chunks.data_ptr()), nch,
+                                              C.c_void_p(freq256.data_ptr())),
+              "hf_symbol_stat_fold_dev")
+        return freq_chunks, freq256
+
     def codebook(self, freq256: torch.Tensor, mode: int = HF_MODE_AUTO,
                  min_freq_threshold: int = 0,
                  out: Optional[DeviceCodebook] = None) -> DeviceCodebook:
@@ -574,21 +598,23 @@ class EntropyAwareHuffmanSystem(_Module):
     def encode_with(self, data_in: torch.Tensor, cb: DeviceCodebook, layout: Optional[int] = None,
                     payload: Optional[torch.Tensor] = None, side: Optional[torch.Tensor] = None,
                     chunk_off: Optional[torch.Tensor] = None, sync: bool = True,
-                    paged: bool = False) -> EncodedStream:
+                    paged: bool = False,
+                    chunk_freq: Optional[torch.Tensor] = None) -> EncodedStream:
         """Pack ``data_in`` with a codebook made elsewhere (another tensor's, a global one summed
         over ranks).  ``paged``: as pages without records (``hf_encode_pages_shared``), sized from
-        per-page counts taken here."""
+        the per-page counts ``chunk_freq`` (``histogram_pages``; taken here when not given)."""
         lay = layout_of(data_in) if layout is None else layout
         data_in = data_in.contiguous()
         n = data_in.numel()
         dev = data_in.device
         nch = (n + HF_CHUNK_SYMS - 1) // HF_CHUNK_SYMS
         if paged:
-            h = self.ctx.handle
-            freq_chunks = torch.empty(max(1, nch) * 256, dtype=torch.int32, device=dev)
-            check(L.lib().hf_symbol_stat_chunks_dev(h, C.c_void_p(_dev_ptr(data_in)), n, lay,
-                                                    C.c_void_p(freq_chunks.data_ptr())),
-                  "hf_symbol_stat_chunks_dev")
+            freq_chunks = chunk_freq
+            if freq_chunks is None:
+                freq_chunks = torch.empty(max(1, nch) * 256, dtype=torch.int32, device=dev)
+                check(L.lib().hf_symbol_stat_chunks_dev(
+                    self.ctx.handle, C.c_void_p(_dev_ptr(data_in)), n, lay,
+                    C.c_void_p(freq_chunks.data_ptr())), "hf_symbol_stat_chunks_dev")
             return self._pack_pages_shared(data_in, lay, cb, freq_chunks, payload, side, chunk_off,
                                            sync)
         own_payload = payload is None

@@ -62,7 +62,8 @@ def main():
     cbs = torch.empty(pages * L.HF_CHUNK_CODEBOOK_BYTES, dtype=torch.uint8, device=dev)
     side = torch.empty(n, dtype=torch.uint8, device=dev) if lay == 1 else None
     cap = pages * (CH // 4 + 256) + 64
-    pay = {k: torch.empty(cap, dtype=torch.int32, device=dev) for k in ("dense", "slotted", "paged")}
+    pay = {k: torch.empty(cap, dtype=torch.int32, device=dev)
+           for k in ("dense", "slotted", "paged", "shared", "dense1")}
     off = {k: torch.empty(pages + 4, dtype=torch.int32, device=dev) for k in pay}
     words_s = torch.empty(pages + 4, dtype=torch.int32, device=dev)
     out = torch.empty(n, dtype=t.dtype, device=dev)
@@ -81,12 +82,22 @@ def main():
     ms["enc dense"] = timed(lambda: lib.hf_encode_chunks(h, P(t), n, lay, P(cbs), P(side), P(pay["dense"]), cap, P(off["dense"]), None))
     ms["enc slotted"] = timed(lambda: lib.hf_encode_chunks_slotted(h, P(t), n, lay, P(cbs), P(freq), P(side), P(pay["slotted"]), cap, P(off["slotted"]), P(words_s), None))
     ms["enc paged"] = timed(lambda: lib.hf_encode_pages(h, P(t), n, lay, P(cbs), P(freq), P(side), P(pay["paged"]), cap, P(off["paged"]), None))
+    # one codebook for the stream: the packed stream and the pages without records
+    freq1 = torch.zeros(256, dtype=torch.int64, device=dev)
+    cb1 = torch.zeros(L.HF_CODEBOOK_DEV_BYTES, dtype=torch.uint8, device=dev)
+    ms["hist (one)"] = timed(lambda: (freq1.zero_(), lib.hf_symbol_stat_dev(h, P(t), n, lay, P(freq1)))[1])
+    ms["fold"] = timed(lambda: (freq1.zero_(), lib.hf_symbol_stat_fold_dev(h, P(freq), pages, P(freq1)))[1])
+    ms["codebook (one)"] = timed(lambda: lib.hf_system_codebook_dev(h, P(freq1), 1, 0, P(cb1)))
+    ms["enc dense1"] = timed(lambda: lib.hf_encode(h, P(t), n, lay, P(cb1), P(side), P(pay["dense1"]), cap, P(off["dense1"]), None))
+    ms["enc shared"] = timed(lambda: lib.hf_encode_pages_shared(h, P(t), n, lay, P(cb1), P(freq), P(side), P(pay["shared"]), cap, P(off["shared"]), None))
     ctx.sync()
+    sb = n if lay == 1 else 0
     words = {k: int(off[k][pages].item()) & 0xFFFFFFFF for k in pay}
-    stored = {"dense": 4 * words["dense"] + 4 * (pages + 1) + 296 * pages,
+    stored = {"dense1": 4 * words["dense1"] + 4 * (pages + 1) + 768,
+              "shared": 4 * words["shared"] + 4 * (pages + 1) + 768,
+              "dense": 4 * words["dense"] + 4 * (pages + 1) + 296 * pages,
               "slotted": 4 * words["slotted"] + 8 * pages + 4 + 296 * pages,
               "paged": 4 * words["paged"] + 4 * (pages + 1)}
-    sb = n if lay == 1 else 0
     out.zero_()
     ms["dec dense"] = timed(lambda: lib.hf_decode_chunks(h, P(pay["dense"]), cap, P(off["dense"]), P(side), n, lay, P(cbs), None, 0, P(out), 0))
     ok = torch.equal(out.view(torch.uint8), t.view(torch.uint8))
@@ -96,16 +107,22 @@ def main():
     out.zero_()
     ms["dec paged"] = timed(lambda: lib.hf_decode_pages(h, P(pay["paged"]), cap, P(off["paged"]), P(side), n, lay, None, None, 0, P(out), 0, 0))
     ok = ok and torch.equal(out.view(torch.uint8), t.view(torch.uint8))
+    out.zero_()
+    ms["dec dense1"] = timed(lambda: lib.hf_decode(h, P(pay["dense1"]), cap, P(off["dense1"]), P(side), n, lay, P(cb1), P(out), 0))
+    ok = ok and torch.equal(out.view(torch.uint8), t.view(torch.uint8))
+    out.zero_()
+    ms["dec shared"] = timed(lambda: lib.hf_decode_pages_shared(h, P(pay["shared"]), cap, P(off["shared"]), P(side), n, lay, P(cb1), None, None, 0, P(out), 0, 0))
+    ok = ok and torch.equal(out.view(torch.uint8), t.view(torch.uint8))
     ctx.sync()
     print(f"{a.kind}: {pages} pages, {n * eb / 1e9:.2f} GB; round trips {'ok' if ok else 'MISMATCH'}")
-    for k in ("dense", "slotted", "paged"):
+    for k in ("dense", "slotted", "paged", "dense1", "shared"):
         print(f"  {k:8s} payload {32.0 * words[k] / n:.4f} bits/symbol, stored ratio "
               f"{n * eb / (stored[k] + sb):.4f}")
     for k, v in ms.items():
         kind = k.split()[-1]
         alg = n * eb
         if k.startswith("enc") or k.startswith("dec"):
-            alg = n * eb + 4.0 * words[kind]
+            alg = n * eb + sb + 4.0 * words[kind]   # elements, side bytes, payload words
         print(f"  {k:12s} {v:8.3f} ms  {n * eb / v / 1e6:8.0f} GB/s of input  "
               f"{alg / v / 1e6 / 8000:6.3f} of peak (algorithmic bytes)")
     if lay != 0 or a.no_read:
