@@ -84,6 +84,8 @@ trait HuffHip extends Library {
                 check: Int): Int
   // per-block codebooks: one EntropyAwareTreeBuilder codebook per 16384-symbol block
   // (entropy_aware_tree_builder.scala:7-19 applied block by block; KV-cache pages)
+  def hf_symbol_stat_pages_dev(ctx: Pointer, dData: Pointer, n: Long, layout: Int,
+                               dFreqChunks: Pointer, dFreq256: Pointer): Int
   def hf_symbol_stat_chunks_dev(ctx: Pointer, dData: Pointer, n: Long, layout: Int,
                                 dFreqChunks: Pointer): Int              // u32[nchunks][256]
   def hf_system_codebook_chunks_dev(ctx: Pointer, dFreqChunks: Pointer, nchunks: Long, mode: Int,

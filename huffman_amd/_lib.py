@@ -113,6 +113,7 @@ SIGNATURES = {
     "hf_num_chunks": (C.c_uint64, [C.c_uint64]),
     "hf_payload_bound_words": (C.c_uint64, [C.c_uint64]),
     "hf_decode": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, C.c_uint64, C.c_int, _vp, _vp, C.c_int]),
+    "hf_symbol_stat_pages_dev": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, _vp, _vp]),
     "hf_symbol_stat_chunks_dev": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, _vp]),
     "hf_system_codebook_chunks_dev": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_uint64, _vp]),
     "hf_system_codebook_chunks_static": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_uint64, _vp]),

@@ -547,8 +547,8 @@ class EntropyAwareHuffmanSystem(_Module):
     def histogram_pages(self, data_in: torch.Tensor, layout: Optional[int] = None,
                         freq_chunks: Optional[torch.Tensor] = None,
                         freq256: Optional[torch.Tensor] = None):
-        """SymbolStat per 16384-symbol page (``hf_symbol_stat_chunks_dev``) and, folded from those
-        (``hf_symbol_stat_fold_dev``), of the whole stream: the data is read once for both.
+        """SymbolStat per 16384-symbol page and of the whole stream from one read of the data
+        (``hf_symbol_stat_pages_dev``).
         Returns (int32[nchunks * 256], int64[256]); ``freq256`` given is added into."""
         lay = layout_of(data_in) if layout is None else layout
         data_in = data_in.contiguous()
@@ -558,13 +558,10 @@ class EntropyAwareHuffmanSystem(_Module):
             freq_chunks = torch.empty(max(1, nch) * 256, dtype=torch.int32, device=data_in.device)
         if freq256 is None:
             freq256 = torch.zeros(256, dtype=torch.int64, device=data_in.device)
-        h = self.ctx.handle
-        check(L.lib().hf_symbol_stat_chunks_dev(h, C.c_void_p(_dev_ptr(data_in)), n, lay,
-                                                C.c_void_p(freq_chunks.data_ptr())),
-              "hf_symbol_stat_chunks_dev")
-        check(L.lib().hf_symbol_stat_fold_dev(h, C.c_void_p(freq_chunks.data_ptr()), nch,
-                                              C.c_void_p(freq256.data_ptr())),
-              "hf_symbol_stat_fold_dev")
+        check(L.lib().hf_symbol_stat_pages_dev(self.ctx.handle, C.c_void_p(_dev_ptr(data_in)), n,
+                                               lay, C.c_void_p(freq_chunks.data_ptr()),
+                                               C.c_void_p(freq256.data_ptr())),
+              "hf_symbol_stat_pages_dev")
         return freq_chunks, freq256
 
     def codebook(self, freq256: torch.Tensor, mode: int = HF_MODE_AUTO,

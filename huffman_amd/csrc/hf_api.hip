@@ -760,6 +760,21 @@ int hf_symbol_stat_chunks_dev(hf_ctx* ctx, const void* d_data, uint64_t n, int l
     return HF_OK;
 }
 
+int hf_symbol_stat_pages_dev(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
+                             uint32_t* d_freq_chunks, uint64_t* d_freq256) {
+    if (!ctx || !layout_ok(layout) || (n && (!d_data || !d_freq_chunks))) return HF_ERR_ARG;
+    if (!aligned16(d_data) || !aligned16(d_freq_chunks) || !aligned16(d_freq256)) return HF_ERR_ALIGN;
+    if (n > (1ull << 40)) return HF_ERR_RANGE;
+    HF_USE_DEVICE(ctx);
+    tic(ctx);
+    hf_launch_hist_pages(d_data, n, norm_layout(layout), d_freq_chunks,
+                         reinterpret_cast<unsigned long long*>(d_freq256), ctx->num_cu, ctx->stream);
+    const hipError_t launch_err = hipGetLastError();  // before the event record can mask it
+    toc(ctx);
+    HF_HIP(launch_err);
+    return HF_OK;
+}
+
 int hf_system_codebook_chunks_dev(hf_ctx* ctx, const uint32_t* d_freq_chunks, uint64_t nchunks,
                                   int mode, uint64_t min_freq_threshold, void* d_chunk_codebooks) {
     if (!ctx || (nchunks && (!d_freq_chunks || !d_chunk_codebooks))) return HF_ERR_ARG;

@@ -130,6 +130,8 @@ void hf_launch_system_block(const void* d_data, uint32_t n, int layout, int mode
                             hipStream_t s);
 void hf_launch_fold_chunks(const uint32_t* d_freq_chunks, uint64_t nchunks,
                            unsigned long long* d_freq256, hipStream_t s);
+void hf_launch_hist_pages(const void* d_data, uint64_t n, int layout, uint32_t* d_freq_chunks,
+                          unsigned long long* d_freq256, int num_cu, hipStream_t s);
 void hf_launch_hist_chunks(const void* d_data, uint64_t n, int layout, uint32_t* d_freq_chunks,
                            hipStream_t s);
 #define HF_CB_BATCH 65536u  // per-block codebooks built per pass through the scratch block

@@ -181,6 +181,133 @@ __global__ __launch_bounds__(kChunkWaves * 64) void hf_k_hist_chunks(
     }
 }
 
+// The same counts for a stream that also wants its own 256 (one codebook for the stream, pages
+// sized from their counts): per-page counts AND the stream's totals from one read of the data.
+// A page is counted by a WORKGROUP: its four wavefronts add into one table of 32 copies of the
+// packed counters (a bank per lane of a 32-lane group: no conflict, no same-address serialisation,
+// however skewed the page), word k of a copy holding bins 2k and 2k+1 as
+// (count of both) | (count of 2k+1) << 16 -- the increment is then 1 | odd << 16, one instruction.
+// 16 KiB of LDS per workgroup leaves room for as many workgroups as the registers allow.
+// Workgroups stay resident and walk the pages, asking for their next page before they count the
+// one they hold; thread t < 128 folds word t of all copies, keeps the running totals of its two
+// bins in registers, and adds them to the stream's counts once, at the end.
+constexpr int kPageCopies = 32;
+constexpr int kPageWords = 128 * kPageCopies;
+
+typedef __attribute__((address_space(3))) uint32_t hf_lds_w32;
+
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void hf_k_hist_pages(
+    const void* __restrict__ data, const uint64_t n, const uint32_t nchunks,
+    uint32_t* __restrict__ freq_chunks, unsigned long long* __restrict__ freq256) {
+    __shared__ __attribute__((aligned(16))) uint32_t h[kPageWords];
+    const uint32_t tid = threadIdx.x;
+    // byte address of this lane's column of the table: word k of copy (lane mod 32) at + 128 k
+    const uint32_t col = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)h +
+                         (tid & (kPageCopies - 1)) * 4u;
+    auto add = [&](const uint32_t pair, const uint32_t inc) {
+        __hip_atomic_fetch_add(reinterpret_cast<hf_lds_w32*>((uintptr_t)((pair * (kPageCopies * 4u)) + col)), inc,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    // the symbols of one 32-bit word of input
+    auto count_word = [&](const uint32_t w) {
+        if (LAYOUT == HF_LAYOUT_BF16_EXP) {  // exponents: bits 7..14 and 23..30
+            add(__builtin_amdgcn_ubfe(w, 8, 7), ((w & 0x80u) << 9) | 1u);
+            add(__builtin_amdgcn_ubfe(w, 24, 7), (__builtin_amdgcn_ubfe(w, 23, 1) << 16) | 1u);
+        } else {
+            add(__builtin_amdgcn_ubfe(w, 1, 7), ((w & 1u) << 16) | 1u);
+            add(__builtin_amdgcn_ubfe(w, 9, 7), ((w & 0x100u) << 8) | 1u);
+            add(__builtin_amdgcn_ubfe(w, 17, 7), (w & 0x10000u) | 1u);
+            add(w >> 25, (__builtin_amdgcn_ubfe(w, 24, 1) << 16) | 1u);
+        }
+    };
+    auto zero = [&]() {
+#pragma unroll
+        for (int k = 0; k < kPageWords / 4 / 256; ++k)
+            reinterpret_cast<uint4*>(h)[k * 256 + tid] = make_uint4(0, 0, 0, 0);
+    };
+    uint32_t acc0 = 0, acc1 = 0;  // bins 2 tid and 2 tid + 1 (tid < 128)
+    // counted page -> its 256 counts; the table is cleared for the next page
+    auto fold = [&](const uint32_t c) {
+        __syncthreads();
+        if (tid < 128) {
+            uint32_t sum = 0;
+#pragma unroll
+            for (int i = 0; i < kPageCopies; ++i)
+                sum += h[tid * kPageCopies + ((i + tid) & (kPageCopies - 1))];
+            // (no half can carry into the other: a page holds at most 16384 symbols)
+            const uint32_t odd = sum >> 16, even = (sum & 0xFFFFu) - odd;
+            reinterpret_cast<uint2*>(freq_chunks + (size_t)c * 256)[tid] = make_uint2(even, odd);
+            acc0 += even;
+            acc1 += odd;
+        }
+        __syncthreads();
+        zero();
+        __syncthreads();
+    };
+
+    constexpr uint32_t kPerVec = LAYOUT == HF_LAYOUT_BF16_EXP ? 8 : 16;
+    constexpr uint32_t kPageVecs = HF_CHUNK_SYMS / kPerVec;
+    constexpr int kVecs = kPageVecs / 256;  // per thread and page: 8 (bf16) or 4
+    const uint32_t nfull = (uint32_t)(n / HF_CHUNK_SYMS);
+    const uint4* const base = reinterpret_cast<const uint4*>(data);
+    // (a page behind the workgroup's last one is read from the stream's last full page instead and
+    // never counted: the loads are issued on every path, so the counted waits stay exact and the
+    // page requested ahead is still in flight while its predecessor is counted)
+    auto load = [&](uint4 (&x)[kVecs], uint32_t c) {
+        c = c < nfull ? c : nfull - 1u;
+        const uint4* p = base + (size_t)c * kPageVecs + tid;
+#pragma unroll
+        for (int k = 0; k < kVecs; ++k) x[k] = stream_load(p + k * 256);
+    };
+    auto count = [&](const uint4 (&x)[kVecs]) {
+#pragma unroll
+        for (int k = 0; k < kVecs; ++k)
+            count_word(x[k].x), count_word(x[k].y), count_word(x[k].z), count_word(x[k].w);
+    };
+    zero();
+    __syncthreads();
+    const uint32_t stride = gridDim.x;
+    uint32_t c = blockIdx.x;
+    if (c < nfull) {
+        uint4 xa[kVecs], xb[kVecs];
+        load(xa, c);
+        for (;;) {
+            load(xb, c + stride);
+            count(xa);
+            fold(c);
+            c += stride;
+            if (c >= nfull) break;
+            load(xa, c + stride);
+            count(xb);
+            fold(c);
+            c += stride;
+            if (c >= nfull) break;
+        }
+    }
+    // the stream's last, partial page
+    if (nfull < nchunks && (nfull % stride) == blockIdx.x) {
+        const uint32_t nvalid = (uint32_t)(n - (uint64_t)nfull * HF_CHUNK_SYMS);
+        const uint4* const pv = base + (size_t)nfull * kPageVecs;
+        const uint32_t nvec = nvalid / kPerVec;
+        for (uint32_t v = tid; v < nvec; v += 256) {
+            const uint4 x = pv[v];
+            count_word(x.x), count_word(x.y), count_word(x.z), count_word(x.w);
+        }
+        for (uint32_t i = nvec * kPerVec + tid; i < nvalid; i += 256) {
+            const uint32_t sym = LAYOUT == HF_LAYOUT_BF16_EXP
+                                     ? (reinterpret_cast<const uint16_t*>(pv)[i] >> 7) & 0xFFu
+                                     : reinterpret_cast<const uint8_t*>(pv)[i];
+            add(sym >> 1, ((sym & 1u) << 16) | 1u);
+        }
+        fold(nfull);
+    }
+    if (freq256 && tid < 128) {
+        if (acc0) atomicAdd(&freq256[2 * tid], (unsigned long long)acc0);
+        if (acc1) atomicAdd(&freq256[2 * tid + 1], (unsigned long long)acc1);
+    }
+}
+
 }  // namespace
 
 // Per-chunk counts folded into a stream's: a workgroup per run of chunks, each of its four
@@ -239,6 +366,25 @@ void hf_launch_hist_chunks(const void* d_data, uint64_t n, int layout, uint32_t*
     else
         hipLaunchKernelGGL(hf_k_hist_chunks<HF_LAYOUT_U8>, dim3(grid), dim3(kChunkWaves * 64), 0, s,
                            d_data, n, (uint32_t)nchunks, d_freq_chunks);
+}
+
+// per-page counts and (d_freq256 given) the stream's totals added into d_freq256
+void hf_launch_hist_pages(const void* d_data, uint64_t n, int layout, uint32_t* d_freq_chunks,
+                          unsigned long long* d_freq256, int num_cu, hipStream_t s) {
+    const uint64_t nchunks = (n + HF_CHUNK_SYMS - 1) / HF_CHUNK_SYMS;
+    if (nchunks == 0) return;
+    // resident workgroups, as many as a CU holds; a thread's 32-bit totals hold 2^18 pages
+    // (registers bound the workgroups per CU: four for 16-bit elements, five for bytes)
+    uint64_t grid = nchunks;
+    const uint64_t cap = (uint64_t)num_cu * (layout == HF_LAYOUT_BF16_EXP ? 4 : 5);
+    if (grid > cap) grid = cap;
+    while (nchunks / grid >= (1ull << 18)) grid *= 2;
+    if (layout == HF_LAYOUT_BF16_EXP)
+        hipLaunchKernelGGL(hf_k_hist_pages<HF_LAYOUT_BF16_EXP>, dim3((unsigned)grid), dim3(256), 0, s,
+                           d_data, n, (uint32_t)nchunks, d_freq_chunks, d_freq256);
+    else
+        hipLaunchKernelGGL(hf_k_hist_pages<HF_LAYOUT_U8>, dim3((unsigned)grid), dim3(256), 0, s,
+                           d_data, n, (uint32_t)nchunks, d_freq_chunks, d_freq256);
 }
 
 void hf_launch_hist(const void* d_data, uint64_t n, int layout, unsigned long long* d_freq256,

@@ -85,7 +85,10 @@ def shard_directory(lo: int, hi: int, payload_words: int, stored_bytes: int,
 class ShardedCodec:
     """Encode / decode this rank's shard of a tensor that is partitioned over the ranks."""
 
-    def __init__(self, ctx=None, global_codebook: bool = True, group=None):
+    def __init__(self, ctx=None, global_codebook: bool = True, group=None, paged: bool = False):
+        """``paged``: store the shard as pages without records (``hf_encode_pages_shared``): per-page
+        and shard counts from one read of the data, the shard's counts summed over the ranks, every
+        page sized exactly from its own counts under the global codebook."""
         from . import api
         self._api = api
         self.ctx = ctx if ctx is not None else api.default_context()
@@ -93,14 +96,18 @@ class ShardedCodec:
         self.decoder = api.ParrallelHuffmanDecoder(ctx=self.ctx)
         self.global_codebook = global_codebook
         self.group = group
+        self.paged = paged
 
     def encode(self, shard: torch.Tensor, mode: int = HF_MODE_AUTO, layout: Optional[int] = None):
         shard = shard.contiguous()
-        freq = self.system.histogram(shard, layout)
+        if self.paged:
+            pages, freq = self.system.histogram_pages(shard, layout)
+        else:
+            pages, freq = None, self.system.histogram(shard, layout)
         if self.global_codebook:
             allreduce_histogram(freq, self.group)
         cb = self.system.codebook(freq, mode)
-        return self.system.encode_with(shard, cb, layout)
+        return self.system.encode_with(shard, cb, layout, paged=self.paged, chunk_freq=pages)
 
     def decode(self, stream, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         return self.decoder.decode(stream, out=out)

@@ -288,6 +288,12 @@ int hf_decode(hf_ctx* ctx, const uint32_t* d_payload, uint64_t payload_words,
 /* SymbolStat per chunk: d_freq_chunks = uint32[nchunks][256], overwritten. */
 int hf_symbol_stat_chunks_dev(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
                               uint32_t* d_freq_chunks);
+/* SymbolStat per chunk AND of the whole stream from one read of the data: d_freq_chunks as
+ * above, and the stream's 256 counts ADDED into d_freq256 (uint64[256]; may be NULL) -- what a
+ * stream with one codebook and pages sized from their own counts needs (hf_encode_pages_shared,
+ * hf_encode_slotted).  The reference counts one stream in one module (symbol_stat.scala:34-38). */
+int hf_symbol_stat_pages_dev(hf_ctx* ctx, const void* d_data, uint64_t n, int layout,
+                             uint32_t* d_freq_chunks, uint64_t* d_freq256);
 /* sort -> entropy decision -> tree -> adjust -> canonical codes -> rank->symbol scatter, once
  * per chunk; d_chunk_codebooks = nchunks records of HF_CHUNK_CODEBOOK_BYTES. */
 int hf_system_codebook_chunks_dev(hf_ctx* ctx, const uint32_t* d_freq_chunks, uint64_t nchunks,

@@ -90,6 +90,25 @@ def test_sharded_codec_runs_the_rccl_all_reduce(hf, orc, nccl_group, monkeypatch
     assert d.is_cuda and d.tolist() == [[lo, hi, s.total_words, s.container_bytes()]]
 
 
+def test_sharded_codec_paged_shard(hf, orc, nccl_group):
+    # the same flow with the shard stored as pages without records: one read of the data for the
+    # per-page and the shard's counts, all-reduce, global codebook, exact page sizes
+    from huffman_amd.dist import ShardedCodec
+    n = 7 * 16384 + 999
+    w = gaussian_bf16(n, seed=78)
+    t = torch.from_numpy(w.view(np.int16)).to(DEV).view(torch.bfloat16)
+    codec = ShardedCodec(global_codebook=True, group=nccl_group, paged=True)
+    s = codec.encode(t, mode=hf.HF_MODE_HUFFMAN)
+    sym, _ = orc.symbolize(w, orc.LAYOUT_BF16_EXP)
+    ec, el = orc.rp_system_codebook(orc.aw_symbol_stat(sym, 256, 64), 64, 0, 16)
+    payload, off = orc.rp_encode_pages_shared(sym, ec, el)
+    assert s.paged and s.total_words == payload.size
+    assert np.array_equal(s.payload[: payload.size].cpu().numpy().view(np.uint32), payload)
+    assert np.array_equal(s.chunk_off[: off.size].cpu().numpy().view(np.uint32), off)
+    assert torch.equal(codec.decode(s).view(torch.int16), t.view(torch.int16))
+    assert codec.directory(s, 0).tolist() == [[0, n, s.total_words, s.container_bytes()]]
+
+
 def test_all_reduce_over_rccl_sums_device_counts(hf, nccl_group):
     # the collective itself on the HIP kernel's own output buffer: one rank, so the sum is the
     # input, and the call must leave the counters usable by the codebook kernel that follows on

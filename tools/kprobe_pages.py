@@ -86,7 +86,12 @@ def main():
     freq1 = torch.zeros(256, dtype=torch.int64, device=dev)
     cb1 = torch.zeros(L.HF_CODEBOOK_DEV_BYTES, dtype=torch.uint8, device=dev)
     ms["hist (one)"] = timed(lambda: (freq1.zero_(), lib.hf_symbol_stat_dev(h, P(t), n, lay, P(freq1)))[1])
+    fq2 = torch.empty_like(freq)
+    ms["hist (pages+one)"] = timed(lambda: (freq1.zero_(), lib.hf_symbol_stat_pages_dev(h, P(t), n, lay, P(fq2), P(freq1)))[1])
+    ok_h = torch.equal(fq2, freq)
     ms["fold"] = timed(lambda: (freq1.zero_(), lib.hf_symbol_stat_fold_dev(h, P(freq), pages, P(freq1)))[1])
+    ok_h = ok_h and int((freq1 - freq.view(pages, 256).sum(0)).abs().sum()) == 0
+    print("per-page counts and stream totals of the one-pass kernel:", "ok" if ok_h else "MISMATCH")
     ms["codebook (one)"] = timed(lambda: lib.hf_system_codebook_dev(h, P(freq1), 1, 0, P(cb1)))
     ms["enc dense1"] = timed(lambda: lib.hf_encode(h, P(t), n, lay, P(cb1), P(side), P(pay["dense1"]), cap, P(off["dense1"]), None))
     ms["enc shared"] = timed(lambda: lib.hf_encode_pages_shared(h, P(t), n, lay, P(cb1), P(freq), P(side), P(pay["shared"]), cap, P(off["shared"]), None))
