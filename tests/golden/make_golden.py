@@ -124,6 +124,36 @@ def main():
     _, lens = O.rp_system_codebook(f, 64, 0, 16)
     out["quality"] = dict(freq=L(f), len=L(lens), result=list(O.aw_quality(f, lens, 32)))
 
+    # --- paged streams (format version 2): pages with their records, pages without -----------
+    prng = np.random.default_rng(77)
+    pages = []
+
+    def crc(w):
+        return int(np.bitwise_xor.reduce(w * np.arange(1, w.size + 1, dtype=np.uint32))) if w.size else 0
+
+    for name, sym in (("3 symbols", np.array([1, 2, 1], np.uint8)),
+                      ("200 geometric", np.minimum(prng.geometric(0.3, 200) - 1, 255).astype(np.uint8)),
+                      ("16385 ramp", (np.arange(16385) % 7).astype(np.uint8)),
+                      ("3 pages mixed", np.concatenate([
+                          np.minimum(prng.geometric(0.05, 16384) - 1, 255),
+                          prng.integers(0, 256, 16384),
+                          np.minimum(prng.geometric(0.6, 9000) - 1, 255)]).astype(np.uint8))):
+        rp, roff, _, _ = O.rp_encode_pages(sym, 0, 1)
+        f = O.aw_symbol_stat(sym, 256, 64)
+        code, lens = O.rp_system_codebook(f, 64, 0, 16)
+        sp, soff = O.rp_encode_pages_shared(sym, code, lens)
+        rec = dict(name=name, n=int(sym.size), record_page_off=L(roff), record_words=int(rp.size),
+                   record_crc=crc(rp), shared_code=L(code), shared_len=L(lens),
+                   shared_page_off=L(soff), shared_words=int(sp.size), shared_crc=crc(sp))
+        if sym.size <= 200:
+            rec["sym"] = L(sym)
+            rec["record_payload"] = L(rp)
+            rec["shared_payload"] = L(sp)
+        else:
+            rec["sym_seed"] = name
+        pages.append(rec)
+    out["pages"] = pages
+
     with open(os.path.join(HERE, "oracle_vectors.json"), "w") as fo:
         json.dump(out, fo, separators=(",", ":"))
     print("wrote", os.path.join(HERE, "oracle_vectors.json"))

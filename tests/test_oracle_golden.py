@@ -104,6 +104,39 @@ def test_golden_streams(orc, gold):
         assert np.array_equal(orc.rp_decode(payload, off, sym.size, s["code"], s["len"]), sym)
 
 
+def _page_inputs():
+    """The inputs of the "pages" vectors that are too long to be stored (generated as in
+    tests/golden/make_golden.py)."""
+    prng = np.random.default_rng(77)
+    g200 = np.minimum(prng.geometric(0.3, 200) - 1, 255).astype(np.uint8)
+    mixed = np.concatenate([np.minimum(prng.geometric(0.05, 16384) - 1, 255),
+                            prng.integers(0, 256, 16384),
+                            np.minimum(prng.geometric(0.6, 9000) - 1, 255)]).astype(np.uint8)
+    return {"200 geometric": g200, "16385 ramp": (np.arange(16385) % 7).astype(np.uint8),
+            "3 pages mixed": mixed}
+
+
+def test_golden_pages(orc, gold):
+    # paged streams: pages with their codebook records, and pages without under one codebook
+    crc = lambda w: int(np.bitwise_xor.reduce(w * np.arange(1, w.size + 1, dtype=np.uint32))) \
+        if w.size else 0
+    made = _page_inputs()
+    for p in gold["pages"]:
+        sym = np.array(p["sym"], np.uint8) if "sym" in p else made[p["name"]]
+        assert sym.size == p["n"]
+        rp, roff, _, _ = orc.rp_encode_pages(sym, 0, 1)
+        assert list(roff) == p["record_page_off"] and rp.size == p["record_words"], p["name"]
+        assert crc(rp) == p["record_crc"], p["name"]
+        sp, soff = orc.rp_encode_pages_shared(sym, p["shared_code"], p["shared_len"])
+        assert list(soff) == p["shared_page_off"] and sp.size == p["shared_words"], p["name"]
+        assert crc(sp) == p["shared_crc"], p["name"]
+        if "sym" in p:
+            assert list(rp) == p["record_payload"] and list(sp) == p["shared_payload"], p["name"]
+        assert np.array_equal(orc.rp_decode_pages(rp, roff, sym.size), sym)
+        assert np.array_equal(orc.rp_decode_pages_shared(sp, soff, sym.size, p["shared_code"],
+                                                         p["shared_len"]), sym)
+
+
 def test_golden_quality(orc, gold):
     q = gold["quality"]
     assert list(orc.aw_quality(q["freq"], q["len"], 32)) == q["result"]
