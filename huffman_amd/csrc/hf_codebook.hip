@@ -32,48 +32,14 @@ struct CbLds {
     uint32_t misc[8];
 };
 
-// Bitonic network over 256 keys, 4 per lane (element e = lane*4 + i), result descending.
-// Strides >= 4 cross lanes through wave shuffles, strides 1 and 2 stay in registers.
-template <class T>
-__device__ __forceinline__ void sort256_desc(T (&k)[4], const int lane) {
-#pragma unroll
-    for (int kk = 2; kk <= 256; kk <<= 1) {
-#pragma unroll
-        for (int j = kk >> 1; j > 0; j >>= 1) {
-            if (j >= 4) {
-                const int lj = j >> 2;
-                const bool lower = (lane & lj) == 0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const T o = __shfl_xor(k[i], lj);
-                    const bool desc = (((lane * 4 + i) & kk) == 0);
-                    // keep the larger where (lower == desc), the smaller elsewhere: the partner's
-                    // key is taken exactly when "mine is larger" and "keep the larger" disagree
-                    // (one compare, one mask operation, one select; keys are distinct)
-                    k[i] = ((k[i] > o) != (lower == desc)) ? o : k[i];
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if ((i & j) == 0) {
-                        const bool desc = (((lane * 4 + i) & kk) == 0);
-                        const T a = k[i], b = k[i | j];
-                        const bool sw = desc ? (a < b) : (a > b);
-                        k[i] = sw ? b : a;
-                        k[i | j] = sw ? a : b;
-                    }
-                }
-            }
-        }
-    }
-}
-
-// The same network for 32-bit keys that are all distinct.  Which lanes keep the larger key of a
-// pair is a property of the lane number alone, so for every stage it is a 64-bit constant; the
-// compiler, to which the lane number is just a value, would recompute it per stage in vector
-// registers.  Here the constant sits in a scalar register pair and is folded into the compare's
-// result by one scalar instruction: two vector instructions per key and stage across lanes,
-// three per pair inside a lane.
+// Bitonic network over 256 distinct keys, 4 per lane (element e = lane * 4 + i), result descending.
+// Strides 1 and 2 stay in a lane's registers.  Across lanes nothing goes through the LDS crossbar
+// and nothing needs an address register: the partner's key comes by a data-parallel-primitive move
+// for lane distances 1, 2 (quad permutes), 4 (half-row mirror, then quad reverse: l ^ 7 ^ 3) and
+// 8 (row rotate by 8 = l ^ 8), and by the row / half-wave swap instructions of gfx950 for 16 and
+// 32.  Which lanes keep the larger key of a pair is a property of the lane number alone, so for
+// every stage it is a 64-bit constant: it sits in a scalar register pair and selects between the
+// pair's maximum and minimum.
 constexpr unsigned long long sort_keep_mask(const int kk, const int lj) {
     unsigned long long m = 0;
     for (int l = 0; l < 64; ++l)
@@ -87,48 +53,135 @@ constexpr unsigned long long sort_asc_mask(const int kk, const int i) {
     return m;
 }
 
-__device__ __forceinline__ void sort256_desc_u32(uint32_t (&k)[4], const int lane) {
+// the value lane (l ^ LJ) holds, LJ = 1, 2, 4, 8
+template <int LJ>
+__device__ __forceinline__ uint32_t lane_xor(const uint32_t v) {
+    static_assert(LJ == 1 || LJ == 2 || LJ == 4 || LJ == 8, "within a row of 16 lanes");
+    if constexpr (LJ == 1) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);  // quad_perm 1,0,3,2
+    } else if constexpr (LJ == 2) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);  // quad_perm 2,3,0,1
+    } else if constexpr (LJ == 4) {
+        const int m = __builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, m, 0x1B, 0xF, 0xF, true);       // quad_perm 3,2,1,0
+    } else {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true);  // row_ror:8
+    }
+}
+
+// one compare-exchange of the keys a lane holds with those of lane ^ LJ (phase KK), 32-bit keys
+template <int KK, int LJ>
+__device__ __forceinline__ void sort_cross_u32(uint32_t (&k)[4]) {
+    constexpr unsigned long long keep = sort_keep_mask(KK, LJ);
 #pragma unroll
-    for (int kk = 2; kk <= 256; kk <<= 1) {
+    for (int i = 0; i < 4; ++i) {
+        uint32_t a, b;  // LJ < 16: own key, partner's key.  LJ >= 16: the two keys of the pair in
+                        // the same order in both lanes
+        if constexpr (LJ >= 16) {
+            const auto sw = LJ == 16 ? __builtin_amdgcn_permlane16_swap(k[i], k[i], false, false)
+                                     : __builtin_amdgcn_permlane32_swap(k[i], k[i], false, false);
+            a = sw[0], b = sw[1];
+        } else {
+            a = k[i], b = lane_xor<LJ>(k[i]);
+        }
+        // the larger key where `keep` says so, the smaller elsewhere: maximum, minimum and a
+        // select on the constant -- no compare result travels through a scalar register.  (Reading
+        // the partner's key through the permutation of the max / min instructions themselves, one
+        // instruction less per key, measured slower: 2430 against 2094 cycles per sort.)
+        const uint32_t hi = a > b ? a : b, lo = a > b ? b : a;
+        uint32_t r;
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(lo), "v"(hi), "s"(keep));
+        k[i] = r;
+    }
+}
+// ... and with 64-bit keys
+template <int KK, int LJ>
+__device__ __forceinline__ void sort_cross_u64(u64 (&k)[4], const int lane) {
+    constexpr unsigned long long keep = sort_keep_mask(KK, LJ);
+    const bool keeps_larger = (keep >> lane) & 1ull;
 #pragma unroll
-        for (int j = kk >> 1; j > 0; j >>= 1) {
-            if (j >= 4) {
-                const int lj = j >> 2;
-                const unsigned long long keep = sort_keep_mask(kk, lj);
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t lo = (uint32_t)k[i], hi = (uint32_t)(k[i] >> 32);
+        u64 a, b;
+        if constexpr (LJ >= 16) {
+            const auto sl = LJ == 16 ? __builtin_amdgcn_permlane16_swap(lo, lo, false, false)
+                                     : __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+            const auto sh = LJ == 16 ? __builtin_amdgcn_permlane16_swap(hi, hi, false, false)
+                                     : __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+            a = ((u64)sh[0] << 32) | sl[0];
+            b = ((u64)sh[1] << 32) | sl[1];
+        } else {
+            a = k[i];
+            b = ((u64)lane_xor<LJ>(hi) << 32) | lane_xor<LJ>(lo);
+        }
+        k[i] = ((a > b) != keeps_larger) ? b : a;
+    }
+}
+
+// strides 1 and 2: both keys in this lane's registers
+template <int KK, int J>
+__device__ __forceinline__ void sort_local_u32(uint32_t (&k)[4]) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t o = __shfl_xor(k[i], lj);
-                    uint32_t r;
-                    asm("v_cmp_gt_u32 vcc, %1, %2\n\t"
-                        "s_xor_b64 vcc, vcc, %3\n\t"
-                        "v_cndmask_b32 %0, %1, %2, vcc"
-                        : "=v"(r)
-                        : "v"(k[i]), "v"(o), "s"(keep)
-                        : "vcc", "scc");  // s_xor_b64 also writes SCC
-                    k[i] = r;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if ((i & j) == 0) {
-                        // descending run: swap when a < b; ascending run: when a > b, which for
-                        // distinct keys is the complement
-                        const unsigned long long asc = sort_asc_mask(kk, i);
-                        uint32_t na, nb;
-                        asm("v_cmp_lt_u32 vcc, %2, %3\n\t"
-                            "s_xor_b64 vcc, vcc, %4\n\t"
-                            "v_cndmask_b32 %0, %2, %3, vcc\n\t"
-                            "v_cndmask_b32 %1, %3, %2, vcc"
-                            : "=&v"(na), "=&v"(nb)
-                            : "v"(k[i]), "v"(k[i | j]), "s"(asc)
-                            : "vcc", "scc");  // s_xor_b64 also writes SCC
-                        k[i] = na;
-                        k[i | j] = nb;
-                    }
-                }
-            }
+    for (int i = 0; i < 4; ++i) {
+        if ((i & J) == 0) {
+            // descending run: the larger key first; ascending run: the smaller
+            const unsigned long long asc = sort_asc_mask(KK, i);
+            const uint32_t a = k[i], b = k[i | J];
+            const uint32_t hi = a > b ? a : b, lo = a > b ? b : a;
+            uint32_t na, nb;
+            asm("v_cndmask_b32_e64 %0, %2, %3, %4\n\t"
+                "v_cndmask_b32_e64 %1, %3, %2, %4"
+                : "=&v"(na), "=&v"(nb)
+                : "v"(hi), "v"(lo), "s"(asc));
+            k[i] = na;
+            k[i | J] = nb;
         }
     }
+}
+template <int KK, int J>
+__device__ __forceinline__ void sort_local_u64(u64 (&k)[4], const int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if ((i & J) == 0) {
+            const bool desc = (((lane * 4 + i) & KK) == 0);
+            const u64 a = k[i], b = k[i | J];
+            const bool sw = desc ? (a < b) : (a > b);
+            k[i] = sw ? b : a;
+            k[i | J] = sw ? a : b;
+        }
+    }
+}
+
+// phase KK of the network: strides KK / 2 .. 1
+template <int KK, int J>
+__device__ __forceinline__ void sort_steps_u32(uint32_t (&k)[4]) {
+    if constexpr (J >= 4) sort_cross_u32<KK, J / 4>(k);
+    else sort_local_u32<KK, J>(k);
+    if constexpr (J > 1) sort_steps_u32<KK, J / 2>(k);
+}
+template <int KK>
+__device__ __forceinline__ void sort_phases_u32(uint32_t (&k)[4]) {
+    if constexpr (KK > 2) sort_phases_u32<KK / 2>(k);
+    sort_steps_u32<KK, KK / 2>(k);
+}
+template <int KK, int J>
+__device__ __forceinline__ void sort_steps_u64(u64 (&k)[4], const int lane) {
+    if constexpr (J >= 4) sort_cross_u64<KK, J / 4>(k, lane);
+    else sort_local_u64<KK, J>(k, lane);
+    if constexpr (J > 1) sort_steps_u64<KK, J / 2>(k, lane);
+}
+template <int KK>
+__device__ __forceinline__ void sort_phases_u64(u64 (&k)[4], const int lane) {
+    if constexpr (KK > 2) sort_phases_u64<KK / 2>(k, lane);
+    sort_steps_u64<KK, KK / 2>(k, lane);
+}
+
+__device__ __forceinline__ void sort256_desc_u32(uint32_t (&k)[4], const int lane) {
+    (void)lane;
+    sort_phases_u32<256>(k);
+}
+__device__ __forceinline__ void sort256_desc(u64 (&k)[4], const int lane) {
+    sort_phases_u64<256>(k, lane);
 }
 
 // SymbolSort with identities: total order (count desc, index asc), which is the order the
@@ -137,12 +190,25 @@ __device__ __forceinline__ void sort256_desc_u32(uint32_t (&k)[4], const int lan
 __device__ void stage_sort(const u64* __restrict__ freq, const int N, u64* sorted,
                            uint16_t* rank2sym, const int lane) {
     u64 k[4];
+    bool small = true;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int e = lane * 4 + i;
-        k[i] = (e < N ? (freq[e] << 8) : 0ull) | (u64)(255 - e);
+        const u64 f = e < N ? freq[e] : 0ull;
+        small = small && f < (1ull << 24);
+        k[i] = (f << 8) | (u64)(255 - e);
     }
-    sort256_desc(k, lane);
+    if (__ballot(!small) == 0ull) {
+        // counts of a block of up to 16 Mi symbols: the keys fit 32 bits, half the moves
+        uint32_t k32[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) k32[i] = (uint32_t)k[i];
+        sort256_desc_u32(k32, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) k[i] = k32[i];
+    } else {
+        sort256_desc(k, lane);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = lane * 4 + i;
