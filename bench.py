@@ -139,7 +139,7 @@ def pmc_traffic(n, lib_hash):
         if d.get("elements_per_gpu") != n or d.get("library_sha256_16") != lib_hash:
             continue
         out = {}
-        for phase, kern in (("hist", "hf_k_hist_chunks"), ("encode", "hf_k_encode_pages"),
+        for phase, kern in (("hist", "hf_k_hist_pages"), ("encode", "hf_k_encode_pages"),
                             ("decode", "hf_k_decode_pages")):
             k = d.get(kern, {})
             if "FETCH_SIZE_KiB_per_launch" in k and "WRITE_SIZE_KiB_per_launch" in k:
