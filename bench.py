@@ -57,11 +57,20 @@ def make_weights(torch, n, device):
     return out
 
 
-def cpu_baseline(torch, w_gpu, sample_elems):
-    """The CPU oracle (a scalar C restatement of the same pipeline) on a bounded sample."""
+def cpu_baseline(torch, w_gpu, sample_elems, gpu_code, gpu_lens, gpu_words, gpu_off):
+    """The CPU oracle (a scalar C restatement of the same pipeline) on a bounded sample; on the way
+    the first pages of the GPU's stream (gpu_words, gpu_off, coded with gpu_code / gpu_lens) are
+    compared with the pages the oracle makes of the same elements and the same codebook."""
     import numpy as np
     from oracle import oracle as orc
     orc.build()
+    npages = gpu_off.numel() - 1
+    mp = min(w_gpu.numel(), npages * 16384)
+    sym, _ = orc.symbolize(w_gpu[:mp].view(torch.int16).cpu().numpy().view(np.uint16),
+                           orc.LAYOUT_BF16_EXP)
+    ref_words, ref_off = orc.rp_encode_pages_shared(sym, gpu_code, gpu_lens)
+    pages_ok = bool(np.array_equal(gpu_off.numpy().view(np.uint32), ref_off)) and bool(
+        np.array_equal(gpu_words.numpy().view(np.uint32), ref_words))
     m = min(sample_elems, w_gpu.numel())
     w = w_gpu[:m].view(torch.int16).cpu().numpy().view(np.uint16)
     t0 = time.perf_counter()
@@ -83,6 +92,7 @@ def cpu_baseline(torch, w_gpu, sample_elems):
                   "symbolize+histogram+codebook+encode+decode, single thread, gcc -O3",
         "encode_GBps": gb / (t2 - t0), "decode_GBps": gb / (t3 - t2),
         "seconds": t3 - t0,
+        "gpu_pages_equal_port": pages_ok, "gpu_pages_compared": int(npages),
     }
     # the same sample on the host cores this process may use: chunk-aligned shards, one thread
     # each (the C calls release the interpreter lock), one global codebook
@@ -317,18 +327,11 @@ def main():
     lbar = bits_ideal / max(1.0, nsym_codebook)
     comp_bytes = 4 * total_words + n + 4 * (nch + 1) + 256 * 3
     stream_ok = True
-    if rank == 0:
-        # the GPU's pages against the oracle's, on the first pages of the tensor
-        import numpy as np
-        from oracle import oracle as orc
-        orc.build()
-        m = min(n, 64 * hf.HF_CHUNK_SYMS)
-        sym, _ = orc.symbolize(w[:m].view(torch.int16).cpu().numpy().view(np.uint16),
-                               orc.LAYOUT_BF16_EXP)
-        ref_payload, ref_off = orc.rp_encode_pages_shared(sym, code, lens)
-        got = payload[:ref_payload.size].cpu().numpy().view(np.uint32)
-        stream_ok = bool(np.array_equal(got, ref_payload)) and bool(np.array_equal(
-            chunk_off[:ref_off.size].cpu().numpy().view(np.uint32), ref_off))
+    # the first pages of the GPU's stream, kept for the CPU leg to compare with its own (the
+    # buffers are reused below)
+    sample_pages = min(nch, 64)
+    sample_off = chunk_off[: sample_pages + 1].cpu()
+    sample_words = payload[: int(sample_off[sample_pages].item()) & 0xFFFFFFFF].cpu()
 
     # the packed stream of format version 1 on the same tensor and codebook, outside the timed
     # region: histogram in one piece, look-back encoder, one wavefront per chunk in the decoder
@@ -419,20 +422,21 @@ def main():
             "compression_mode": mode, "entropy_q16": ent,
             "tree_quality": quality,
             "roundtrip_bit_exact": ok,
-            "pages_equal_oracle_on_sample": stream_ok,
             "dense_v1": dense,
             "library_sha256_16": lib_hash,
             "roofline": dict(roof[dominant], kernel=dominant),
             "roofline_all": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(torch, w, args.cpu_sample)
+            line["cpu_baseline"] = cpu_baseline(torch, w, args.cpu_sample, code, lens, sample_words,
+                                                sample_off)
+            stream_ok = line["cpu_baseline"]["gpu_pages_equal_port"]
         print(json.dumps(line), flush=True)
     if use_dist:
         barrier()
         dist.destroy_process_group()
     if not ok or not stream_ok:
-        raise SystemExit("round trip mismatch" if not ok else "pages differ from the oracle's")
+        raise SystemExit("round trip mismatch" if not ok else "pages differ from the CPU port's")
 
 
 if __name__ == "__main__":

@@ -726,15 +726,7 @@ class EntropyAwareHuffmanSystem(_Module):
         lay = layout_of(data_in) if layout is None else layout
         n, dev, h = data_in.numel(), data_in.device, self.ctx.handle
         nch = (n + HF_CHUNK_SYMS - 1) // HF_CHUNK_SYMS
-        with torch.cuda.stream(self.ctx.stream):
-            freq = torch.zeros(256, dtype=torch.int64, device=dev)
-        freq_chunks = torch.empty(max(1, nch) * 256, dtype=torch.int32, device=dev)
-        check(L.lib().hf_symbol_stat_chunks_dev(h, C.c_void_p(_dev_ptr(data_in)), n, lay,
-                                                C.c_void_p(freq_chunks.data_ptr())),
-              "hf_symbol_stat_chunks_dev")
-        check(L.lib().hf_symbol_stat_fold_dev(h, C.c_void_p(freq_chunks.data_ptr()), nch,
-                                              C.c_void_p(freq.data_ptr())),
-              "hf_symbol_stat_fold_dev")
+        freq_chunks, freq = self.histogram_pages(data_in, lay)  # one read for both
         cb = self.codebook(freq, mode, min_freq_threshold)
         chunk_off = torch.empty(((nch + 1 + 3) // 4) * 4, dtype=torch.int32, device=dev)
         chunk_words = torch.empty(((nch + 3) // 4) * 4 + 4, dtype=torch.int32, device=dev)

@@ -227,3 +227,44 @@ def test_shared_pages_empty_input(hf):
     blob = s.to_container(sys_.ctx)
     back = hf.EncodedStream.from_container(blob, ctx=sys_.ctx)
     assert back.n == 0 and back.paged
+
+
+@pytest.mark.parametrize("layout", ["u8", "bf16"])
+def test_page_counts_and_stream_totals_from_one_read(hf, orc, layout):
+    # hf_symbol_stat_pages_dev against the oracle's SymbolStat per page and over the stream: sizes
+    # around page boundaries, more pages than resident workgroups, totals ADDED into d_freq256,
+    # and the call without the totals
+    L = hf.L
+    lib = L.lib()
+    ctx = hf.Context(0)
+    rng = np.random.default_rng(31)
+    P = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
+    for n in (0, 1, 7, CH - 1, CH, CH + 1, 5 * CH + 77, 3000 * CH + 12345):
+        if layout == "bf16":
+            bits = gaussian_bf16(max(n, 1), seed=n % 97)[:n]
+            t = to_dev(bits.view(np.int16)) if n else torch.empty(0, dtype=torch.int16, device=DEV)
+            sym, _ = orc.symbolize(bits, orc.LAYOUT_BF16_EXP) if n else (np.zeros(0, np.uint8), None)
+            lay = hf.HF_LAYOUT_BF16_EXP
+        else:
+            sym = np.minimum(rng.geometric(0.05, n) - 1, 255).astype(np.uint8)
+            t = to_dev(sym) if n else torch.empty(0, dtype=torch.uint8, device=DEV)
+            lay = hf.HF_LAYOUT_U8
+        nch = (n + CH - 1) // CH
+        pages = torch.full((max(nch, 1) * 256,), -1, dtype=torch.int32, device=DEV)
+        tot = torch.full((256,), 5, dtype=torch.int64, device=DEV)
+        assert lib.hf_symbol_stat_pages_dev(ctx.handle, P(t) if n else None, n, lay, P(pages), P(tot)) == 0
+        ctx.sync()
+        want = np.zeros((max(nch, 1), 256), np.int64)
+        for c in range(nch):
+            want[c] = np.bincount(sym[c * CH:(c + 1) * CH], minlength=256)
+        got = pages.cpu().numpy().reshape(-1, 256)
+        assert np.array_equal(got[:nch], want[:nch]), (layout, n)
+        assert np.array_equal(tot.cpu().numpy(), want[:nch].sum(0) + 5), (layout, n)
+        if n:
+            assert np.array_equal(want[:nch].sum(0).astype(np.uint64),
+                                  np.asarray(orc.aw_symbol_stat(sym, 256, 64), np.uint64))
+            again = torch.zeros_like(pages)
+            assert lib.hf_symbol_stat_pages_dev(ctx.handle, P(t), n, lay, P(again), None) == 0
+            ctx.sync()
+            assert torch.equal(again[: nch * 256], pages[: nch * 256])
+    assert lib.hf_symbol_stat_pages_dev(ctx.handle, None, 5, hf.HF_LAYOUT_U8, None, None) == L.HF_ERR_ARG
