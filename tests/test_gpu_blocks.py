@@ -326,6 +326,26 @@ def test_seeded_random_pages_against_the_oracle(hf, orc):
             assert np.array_equal(got[a:a + int(words[c])], payload[off[c]:off[c + 1]]), c
             assert not got[a + int(words[c]):int(starts[c + 1])].any(), c
         assert torch.equal(hf.ParrallelHuffmanDecoder().decode(ss), t)
+        # ... as pages with their codebook records (exact sizes, four sub-decoders per page) ...
+        mreq = {hf.HF_MODE_HUFFMAN: 1, hf.HF_MODE_AUTO: 2, hf.HF_MODE_BYPASS: 0}[mode]
+        sp = sys_.encode_blocks(t, mode=mode, paged=True)
+        ppay, poff, _, _ = orc.rp_encode_pages(sym, 0, mreq)
+        assert sp.total_words == ppay.size
+        assert np.array_equal(sp.chunk_off[: P + 1].cpu().numpy().view(np.uint32), poff)
+        assert np.array_equal(sp.payload[: ppay.size].cpu().numpy().view(np.uint32), ppay)
+        assert torch.equal(hf.ParrallelHuffmanDecoder().decode(sp), t)
+        # ... and as pages without records under the stream's one codebook
+        if mode != hf.HF_MODE_AUTO:
+            so = sys_.encode(t, mode=mode, paged=True)
+            if mode == hf.HF_MODE_BYPASS:
+                c1, l1 = np.arange(256, dtype=np.uint16), np.full(256, 8, np.uint8)
+            else:
+                c1, l1 = orc.rp_system_codebook(orc.aw_symbol_stat(sym, 256, 64), 64, 0, 16)
+            spay, soff = orc.rp_encode_pages_shared(sym, c1, l1)
+            assert so.total_words == spay.size
+            assert np.array_equal(so.chunk_off[: P + 1].cpu().numpy().view(np.uint32), soff)
+            assert np.array_equal(so.payload[: spay.size].cpu().numpy().view(np.uint32), spay)
+            assert torch.equal(hf.ParrallelHuffmanDecoder().decode(so), t)
     # HF_MODE_BEST: per page, Huffman only where it pays; the stream still round-trips
     s = sys_.encode_blocks(t, mode=hf.HF_MODE_BEST)
     for c in range(P):
