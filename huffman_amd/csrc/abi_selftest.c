@@ -52,6 +52,19 @@ int main(void) {
                 CHECK(info.total_bytes % 16 == 0 && info.off_payload % 16 == 0);
                 CHECK(info.total_bytes >= info.off_payload + 16);
             }
+    /* ... with a placement (wire format version 2): slotted streams carry a words array, paged
+       streams with records carry no codebook section, paged streams without carry the one */
+    for (uint64_t n = 0; n < 100000; n += 7777)
+        for (int kind = 0; kind < 2; ++kind)
+            for (int placement = 0; placement < 3; ++placement) {
+                CHECK(hf_container_plan_placed(n, HF_LAYOUT_U8, kind, placement, n / 3, &info) == HF_OK);
+                CHECK(info.placement == (uint32_t)placement && info.total_bytes % 16 == 0);
+                CHECK((info.off_chunk_words != 0) == (placement == HF_PLACEMENT_SLOTTED));
+                CHECK((info.off_codebook == 0) ==
+                      (placement == HF_PLACEMENT_PAGED && kind == HF_CODEBOOK_PER_CHUNK));
+            }
+    CHECK(hf_container_plan_placed(1, 0, 0, 3, 1, &info) == HF_ERR_ARG);
+    CHECK(hf_pages_bound_words(0) == 0 && hf_pages_bound_words(16385) == 2ull * hf_pages_bound_words(1));
     CHECK(hf_container_plan(1, 9, 0, 1, &info) == HF_ERR_ARG);
     CHECK(hf_container_plan(1, 0, 0, 1, NULL) == HF_ERR_ARG);
 
@@ -64,12 +77,27 @@ int main(void) {
     CHECK(hf_decode_chunks_to(NULL, NULL, 0, NULL, NULL, 0, 0, NULL, NULL, NULL, 0, NULL, 0, 0) ==
           HF_ERR_ARG);
     CHECK(hf_last_hip_error(NULL) == 0);
+    CHECK(hf_ctx_reserve(NULL, 0, HF_RESERVE_ALL) == HF_ERR_ARG);
+    CHECK(hf_zero_dev(NULL, NULL, 0) == HF_ERR_ARG);
+    CHECK(hf_symbol_stat_pages_dev(NULL, NULL, 0, 0, NULL, NULL) == HF_ERR_ARG);
+    CHECK(hf_symbol_stat_allreduce(NULL, NULL, NULL) == HF_ERR_ARG);
+    CHECK(hf_encode_pages(NULL, NULL, 0, 0, NULL, NULL, NULL, NULL, 0, NULL, NULL) == HF_ERR_ARG);
+    CHECK(hf_encode_pages_shared(NULL, NULL, 0, 0, NULL, NULL, NULL, NULL, 0, NULL, NULL) == HF_ERR_ARG);
+    CHECK(hf_decode_pages(NULL, NULL, 0, NULL, NULL, 0, 0, NULL, NULL, 0, NULL, 0, 0) == HF_ERR_ARG);
+    CHECK(hf_decode_pages_shared(NULL, NULL, 0, NULL, NULL, 0, 0, NULL, NULL, NULL, 0, NULL, 0, 0) ==
+          HF_ERR_ARG);
+    CHECK(hf_page_codebook_download(NULL, NULL, 0, NULL, 0, NULL, NULL, NULL, NULL) == HF_ERR_ARG);
+    CHECK(hf_system_codebook_chunks_static(NULL, NULL, 0, HF_MODE_HUFFMAN, 0, NULL) == HF_ERR_ARG);
 
     hf_ctx* ctx = NULL;
     const int rc = hf_ctx_create(&ctx, 0, NULL);
     if (rc == HF_OK) {
         CHECK(ctx != NULL);
         CHECK(hf_flush(ctx) == HF_OK);
+        CHECK(hf_ctx_reserve(ctx, 1u << 20, HF_RESERVE_ALL) == HF_OK);
+        CHECK(hf_ctx_reserve(ctx, 1, 0x80u) == HF_ERR_ARG);
+        CHECK(hf_zero_dev(ctx, NULL, 0) == HF_OK);
+        CHECK(hf_symbol_stat_allreduce(ctx, NULL, NULL) == HF_ERR_ARG);
         CHECK(hf_ctx_destroy(ctx) == HF_OK);
     } else {
         CHECK(rc == HF_ERR_HIP && ctx == NULL);  /* no GPU here: a clean error, no fallback */
