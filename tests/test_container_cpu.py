@@ -109,3 +109,37 @@ def test_oracle_container_v2_fields(orc):
     o_words = struct.unpack_from("<Q", raw, 112)[0]
     assert struct.unpack_from("<I", raw, 104)[0] == 1 and o_words % 16 == 0
     assert np.array_equal(np.frombuffer(raw, "<u4", nch, o_words), w2)
+
+
+def test_oracle_pages_without_records(orc):
+    """Pages under one codebook: 49 words plus the strings each, round trips at ragged sizes, the
+    container with the stream's codebook section, and what damage the decoder reports."""
+    rng = np.random.default_rng(10)
+    for n in (1, 63, 16384, 16385, 3 * 16384 + 5):
+        sym = np.minimum(rng.geometric(0.15, n) - 1, 255).astype(np.uint8)
+        code, lens = orc.rp_system_codebook(orc.aw_symbol_stat(sym, 256, 64), 64, 0, 16)
+        payload, off = orc.rp_encode_pages_shared(sym, code, lens)
+        nch = (n + 16383) // 16384
+        for c in range(nch):
+            bits = int(lens[sym[c * 16384:(c + 1) * 16384]].astype(np.int64).sum())
+            assert int(off[c + 1]) - int(off[c]) == orc.shared_page_words(bits) == 49 + (bits + 31) // 32
+            assert int(payload[off[c]]) == (bits << 10) | (1 << 29)
+        assert np.array_equal(orc.rp_decode_pages_shared(payload, off, n, code, lens), sym)
+    raw = orc.container_pack(n, orc.LAYOUT_U8, payload, off, code=code, lens=lens, mode=1,
+                             entropy_q16=7, placement=2).tobytes()
+    ver, hdr, layout, kind = struct.unpack_from("<4I", raw, 8)
+    assert (ver, layout, kind) == (2, 0, 0) and struct.unpack_from("<I", raw, 104)[0] == 2
+    o_cb, o_off, o_side, o_pay = struct.unpack_from("<4Q", raw, 64)
+    assert o_cb == 128 and o_off == 128 + 768 and o_side == 0
+    assert np.array_equal(np.frombuffer(raw, "<u2", 256, o_cb), code)
+    assert np.array_equal(np.frombuffer(raw, "u1", 256, o_cb + 512), lens)
+    back = orc.rp_decode_pages_shared(np.frombuffer(raw, "<u4", payload.size, o_pay),
+                                      np.frombuffer(raw, "<u4", nch + 1, o_off), n, code, lens)
+    assert np.array_equal(back, sym)
+    # a page that claims a record, a size that disagrees with the offsets, region lengths that do
+    # not add up: all refused
+    for word, flip in ((int(off[1]), 1 << 29), (int(off[1]), 1 << 12), (int(off[2]) + 3, 0x7)):
+        hurt = payload.copy()
+        hurt[word] ^= np.uint32(flip)
+        with pytest.raises(ValueError):
+            orc.rp_decode_pages_shared(hurt, off, n, code, lens)
