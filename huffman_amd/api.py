@@ -599,20 +599,15 @@ class EntropyAwareHuffmanSystem(_Module):
                     chunk_freq: Optional[torch.Tensor] = None) -> EncodedStream:
         """Pack ``data_in`` with a codebook made elsewhere (another tensor's, a global one summed
         over ranks).  ``paged``: as pages without records (``hf_encode_pages_shared``), sized from
-        the per-page counts ``chunk_freq`` (``histogram_pages``; taken here when not given)."""
+        the per-page counts ``chunk_freq`` (``histogram_pages``) when given, else placed while they
+        are encoded (one read of the data, no counts; the same stream bit for bit)."""
         lay = layout_of(data_in) if layout is None else layout
         data_in = data_in.contiguous()
         n = data_in.numel()
         dev = data_in.device
         nch = (n + HF_CHUNK_SYMS - 1) // HF_CHUNK_SYMS
         if paged:
-            freq_chunks = chunk_freq
-            if freq_chunks is None:
-                freq_chunks = torch.empty(max(1, nch) * 256, dtype=torch.int32, device=dev)
-                check(L.lib().hf_symbol_stat_chunks_dev(
-                    self.ctx.handle, C.c_void_p(_dev_ptr(data_in)), n, lay,
-                    C.c_void_p(freq_chunks.data_ptr())), "hf_symbol_stat_chunks_dev")
-            return self._pack_pages_shared(data_in, lay, cb, freq_chunks, payload, side, chunk_off,
+            return self._pack_pages_shared(data_in, lay, cb, chunk_freq, payload, side, chunk_off,
                                            sync)
         own_payload = payload is None
         if own_payload:
@@ -655,7 +650,7 @@ class EntropyAwareHuffmanSystem(_Module):
         def run_pages(buf):
             return L.lib().hf_encode_pages_shared(
                 self.ctx.handle, C.c_void_p(_dev_ptr(data_in)), n, lay, C.c_void_p(cb.ptr),
-                C.c_void_p(freq_chunks.data_ptr()), C.c_void_p(_dev_ptr(side)),
+                C.c_void_p(_dev_ptr(freq_chunks)), C.c_void_p(_dev_ptr(side)),
                 C.c_void_p(buf.data_ptr()), buf.numel(), C.c_void_p(chunk_off.data_ptr()),
                 C.byref(total) if sync else None)
         own_payload = payload is None
@@ -696,19 +691,28 @@ class EntropyAwareHuffmanSystem(_Module):
     # -- whole path ----------------------------------------------------------------------------
     def encode(self, data_in: torch.Tensor, mode: int = HF_MODE_AUTO,
                layout: Optional[int] = None, min_freq_threshold: int = 0,
-               slotted: bool = False, paged: bool = False) -> EncodedStream:
+               slotted: bool = False, paged: bool = False,
+               page_counts: bool = True) -> EncodedStream:
         """``slotted``: one codebook for the stream, every chunk in a slot sized from the chunk's
         own counts (``hf_encode_slotted``): 1.5-3 % more words, written faster.
 
         ``paged``: one codebook for the stream, the chunks stored as pages without records
-        (``hf_encode_pages_shared``): exact sizes from the chunks' counts, no look-ahead words, no
-        look-back; decoded by four sub-decoders per page from tables made once per call."""
+        (``hf_encode_pages_shared``): exact sizes, no look-ahead words; decoded by four
+        sub-decoders per page from tables made once per call.  With ``page_counts`` (the faster
+        way when the stream's counts have to be taken anyway) the pages are placed beforehand from
+        per-page counts taken with the stream's in one read (``histogram_pages``), which the stream
+        keeps in ``chunk_freq``; without, SymbolStat of the stream alone, and the encoder places
+        the pages while it encodes them.  Both give the same stream."""
         data_in = data_in.contiguous()
         if layout in FIELD_LAYOUTS:
             sym, side = self.split_fields(data_in, layout)
-            s = self.encode(sym, mode, HF_LAYOUT_U8, min_freq_threshold, slotted, paged)
+            s = self.encode(sym, mode, HF_LAYOUT_U8, min_freq_threshold, slotted, paged, page_counts)
             s.layout, s.side, s.dtype = layout, side, data_in.dtype
             return s
+        if paged and not page_counts:
+            freq = self.histogram(data_in, layout)
+            cb = self.codebook(freq, mode, min_freq_threshold)
+            return self.encode_with(data_in, cb, layout, paged=True)
         if slotted or paged:
             return self._encode_slotted(data_in, mode, layout, min_freq_threshold, paged)
         # one chunk: counted where the codebook is built (larger blocks may still ask for it, but a

@@ -328,8 +328,10 @@ int hf_ctx_reserve(hf_ctx* ctx, uint64_t max_n, unsigned flags) {
     }
     if (flags & HF_RESERVE_CODEBOOKS)
         if (int rc = ensure_cbscratch(ctx)) return rc;
-    if (flags & HF_RESERVE_PLACED)
+    if (flags & HF_RESERVE_PLACED) {
         if (int rc = ensure_scan_aux(ctx, nchunks)) return rc;
+        if (int rc = ensure_desc(ctx, nchunks)) return rc;  // (pages placed while they are encoded)
+    }
     return HF_OK;
 }
 
@@ -1042,7 +1044,10 @@ static int encode_pages_common(hf_ctx* ctx, const void* d_data, uint64_t n, int 
                                uint64_t* h_total_words) {
     const void* const cbp = d_codebook ? d_codebook : d_chunk_codebooks;
     if (!ctx || !d_page_off || !layout_ok(layout)) return HF_ERR_ARG;
-    if (n && (!d_data || !d_payload || !cbp || !d_freq_chunks)) return HF_ERR_ARG;
+    // (a stream with one codebook may come without per-page counts: its pages are then placed
+    // while they are encoded)
+    const bool once = d_codebook && !d_freq_chunks;
+    if (n && (!d_data || !d_payload || !cbp || (!d_freq_chunks && !once))) return HF_ERR_ARG;
     const int lay = norm_layout(layout);
     if (lay == HF_LAYOUT_BF16_EXP && n && !d_side) return HF_ERR_ARG;
     if (!aligned16(d_data) || !aligned16(d_side) || !aligned16(d_payload) ||
@@ -1051,9 +1056,22 @@ static int encode_pages_common(hf_ctx* ctx, const void* d_data, uint64_t n, int 
     if (n > (1ull << 40)) return HF_ERR_RANGE;
     HF_USE_DEVICE(ctx);
     const uint64_t nchunks = hf_num_chunks(n);
-    if (int rc = ensure_scan_aux(ctx, nchunks)) return rc;
+    if (once) {
+        if (int rc = ensure_desc(ctx, nchunks)) return rc;
+    } else if (int rc = ensure_scan_aux(ctx, nchunks)) {
+        return rc;
+    }
     if (nchunks == 0) {
         zero_words(d_page_off, 1, ctx->stream);
+    } else if (once) {
+        tic(ctx);
+        zero_words(reinterpret_cast<uint32_t*>(ctx->d_desc + 2), nchunks * 2, ctx->stream);
+        hf_launch_encode_pages_once(d_data, n, lay, reinterpret_cast<const hf_cb_dev*>(d_codebook),
+                                    d_side, d_payload, payload_cap_words, d_page_off, ctx->d_desc + 2,
+                                    ctx->d_ctl + 1, ctx->stream);
+        const hipError_t launch_err = hipGetLastError();
+        toc(ctx);
+        HF_HIP(launch_err);
     } else {
         tic(ctx);
         hf_launch_encode_pages(d_data, n, lay, reinterpret_cast<const hf_chunk_cb*>(d_chunk_codebooks),

@@ -166,6 +166,10 @@ void hf_launch_encode_pages(const void* d_data, uint64_t n, int layout, const hf
                             const hf_cb_dev* shared_cb, const uint32_t* d_freq_chunks, uint8_t* d_side,
                             uint32_t* d_payload, uint64_t cap_words, uint32_t* d_page_off,
                             unsigned long long* d_scan_aux, uint32_t* d_err, hipStream_t s);
+void hf_launch_encode_pages_once(const void* d_data, uint64_t n, int layout, const hf_cb_dev* shared_cb,
+                                 uint8_t* d_side, uint32_t* d_payload, uint64_t cap_words,
+                                 uint32_t* d_page_off, unsigned long long* d_desc, uint32_t* d_err,
+                                 hipStream_t s);
 size_t hf_page_tab_image_bytes(void);
 void hf_launch_decode_pages(const uint32_t* d_payload, uint64_t payload_words,
                             const uint32_t* d_page_off, const uint8_t* d_side, uint64_t n,

@@ -459,6 +459,301 @@ __global__ __launch_bounds__(256) void hf_k_encode_pages(
                                            off1 - off0, err);
 }
 
+// ---- encoder of a stream with one codebook, in one read of the data -----------------------------
+//
+// Without per-page counts a page's size is only known once its symbols have been looked up, so its
+// place is found while it is encoded: every page publishes its size in a descriptor as soon as the
+// first pass has added up its bits, packs its strings into the LDS image, and then sums the
+// descriptors in front of its own back to the nearest one that already holds an inclusive prefix
+// (decoupled look-back).  The image is built without knowing the alignment of its place, so the
+// copy-out reads it word by word and still writes 16-byte pieces.  The stream is the same, bit for
+// bit, as the one placed from per-page counts.
+//
+// A page waits only for pages with lower numbers, and a GPU starts the workgroups of a
+// one-dimensional grid in the order of their numbers, so the page with the lowest number among
+// those not yet finished is always running and never waits: the walk cannot deadlock.  It is
+// bounded all the same (one second on the 100 MHz clock, and at once when another page has given
+// up): the call then reports HF_ERR_TIMEOUT and the stream is not complete.
+constexpr u64 kPgAggregate = 1ull << 62;
+constexpr u64 kPgPrefix = 2ull << 62;
+constexpr u64 kPgValueMask = (1ull << 62) - 1ull;
+constexpr u64 kPgSpinTicks = 100000000ull;
+constexpr u64 kPgGaveUp = ~0ull;
+#ifndef HF_PAGE_LOOK_K
+#define HF_PAGE_LOOK_K 4
+#endif
+constexpr int kPgLookK = HF_PAGE_LOOK_K;  // descriptors per lane and pass: a pass covers 256 pages
+
+// words in front of page c (c >= 1); kPgGaveUp after a timeout.  One wavefront, all lanes.
+__device__ u64 page_lookback(const u64* desc, const uint32_t c, const int lane, uint32_t* err) {
+    u64 excl = 0;
+    long long idx = (long long)c - 1;
+    uint32_t spins = 0;
+    u64 t0 = 0;
+    while (idx >= 0) {
+        u64 d[kPgLookK];
+#pragma unroll
+        for (int k = 0; k < kPgLookK; ++k) d[k] = 0;
+        for (;;) {
+            // (only descriptors not yet seen valid are read again)
+#pragma unroll
+            for (int k = 0; k < kPgLookK; ++k) {
+                const long long j = idx - 64 * k - lane;
+                if ((d[k] >> 62) == 0)  // in front of page 0: prefix 0
+                    d[k] = j >= 0 ? __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                  : kPgPrefix;
+            }
+            // the nearest prefix (step kf, lane lf); every descriptor nearer than it must hold a size
+            int kf = kPgLookK;
+            bool holes = false;
+            u64 v = 0;
+#pragma unroll
+            for (int k = 0; k < kPgLookK; ++k) {
+                const u64 inv = __ballot((d[k] >> 62) == 0);
+                const u64 pre = __ballot((d[k] >> 62) == 2);
+                if (kf == kPgLookK) {  // (wave-uniform)
+                    u64 upto = ~0ull;
+                    if (pre) {
+                        kf = k;
+                        const int lf = (int)__builtin_ctzll(pre);
+                        upto = lf >= 63 ? ~0ull : ((2ull << lf) - 1ull);
+                    }
+                    holes = holes || (inv & upto) != 0;
+                    v += ((upto >> lane) & 1ull) ? (d[k] & kPgValueMask) : 0ull;
+                }
+            }
+            if (!holes) {
+                excl += hf_wave_sum_u64(v);
+                if (kf < kPgLookK) return excl;
+                break;
+            }
+            if ((++spins & 15u) == 0) {
+                const u64 now = __builtin_amdgcn_s_memrealtime();
+                if (t0 == 0) t0 = now;
+                const uint32_t seen = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (now - t0 > kPgSpinTicks || (seen & HF_KERR_TIMEOUT) != 0) {
+                    if (lane == 0) atomicOr(err, HF_KERR_TIMEOUT);
+                    return kPgGaveUp;
+                }
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        idx -= 64 * kPgLookK;
+    }
+    return excl;
+}
+
+// The place of page c (`words` long): wavefront 0 walks back, everybody learns the result -- the
+// offset in the low half, 1 in the high half if the page may be written.  A page that does not fit,
+// or whose walk gave up, writes nothing (its descriptor is completed all the same, so that the
+// pages behind it end too).  All 256 threads call.
+__device__ __forceinline__ u64 page_place(EncPageLds& L, u64* desc, const uint32_t c,
+                                          const uint32_t nchunks, const u64 limit, const uint32_t words,
+                                          uint32_t* __restrict__ page_off, uint32_t* err) {
+    const int lane = hf_lane();
+    if (threadIdx.x < 64u) {
+        // (a walk that gave up anywhere leaves sums that mean nothing: nobody writes after it)
+        const uint32_t seen = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 e = c == 0 ? 0ull : page_lookback(desc, c, lane, err);
+        if (lane == 0) {
+            const bool gave_up = e == kPgGaveUp || (seen & HF_KERR_TIMEOUT) != 0;
+            const u64 end = gave_up ? 0ull : e + (u64)words;
+            if (c != 0)
+                __hip_atomic_store(&desc[c], kPgPrefix | end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool fits = !gave_up && end <= limit;
+            if (!gave_up && !fits) atomicOr(err, HF_KERR_OVERFLOW);
+            L.red[0] = (uint32_t)e;
+            L.red[1] = fits ? 1u : 0u;
+            page_off[c] = fits ? (uint32_t)e : 0u;
+            if (c + 1u == nchunks) {
+                const uint32_t t = fits ? (uint32_t)end : 0xFFFFFFFFu;
+                page_off[nchunks] = t;
+                err[1] = t;  // (the call's total, beside the error word)
+            }
+        }
+    }
+    __syncthreads();
+    return (u64)L.red[0] | ((u64)L.red[1] << 32);
+}
+
+// copy out: image word k goes to payload word off0 + k; 16-byte pieces of the payload where the
+// page covers them whole, single words at its two ends (the image was built without knowing the
+// alignment of its place, so it is read word by word)
+__device__ __forceinline__ void page_copy_out(const EncPageLds& L, uint32_t* __restrict__ payload,
+                                              const uint32_t off0, const uint32_t ncopy) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t a0 = off0 & 3u;
+    uint32_t* const dst = payload + (off0 - a0);  // 16-byte aligned
+    for (uint32_t g = tid; g * 4u < a0 + ncopy; g += 256u) {
+        const uint32_t k0 = g * 4u;
+        if (k0 >= a0 && k0 + 4u <= a0 + ncopy) {
+            const uint32_t* const src = L.img + (k0 - a0);
+            *reinterpret_cast<uint4*>(dst + k0) = make_uint4(src[0], src[1], src[2], src[3]);
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i)
+                if (k0 + i >= a0 && k0 + i < a0 + ncopy) dst[k0 + i] = L.img[k0 + i - a0];
+        }
+    }
+}
+
+// A page whose strings are too long for the LDS image (Huffman forced on data it does not
+// compress): they go straight to their place off0, known by now.  Nothing was kept across the
+// walk -- every lane fetches its 64 symbols once more, one at a time, and packs them with a loop
+// that needs few registers (this path is rare, and its registers would otherwise set the occupancy
+// of the whole kernel).  L holds the encoder table, the header, the region lengths and rstart[];
+// the side bytes were written by the first pass.
+template <int LAYOUT>
+__device__ __forceinline__ void encode_page_big(EncPageLds& L, const void* chunk_in,
+                                                const uint32_t nvalid, uint32_t* __restrict__ payload,
+                                                const uint32_t off0) {
+    const int lane = hf_lane();
+    const uint32_t tid = threadIdx.x;
+    const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    constexpr uint32_t hdr_words = 1u + kGap;
+    const uint32_t B = L.rstart[128];
+    const uint32_t wn = (B + 31u) / 32u;
+    uint32_t* const glob_str = payload + off0 + hdr_words;
+    for (uint32_t k = tid; k < wn; k += 256u) glob_str[k] = 0u;
+    __threadfence();
+    __syncthreads();
+    const bool back = q >= 2;
+    const uint32_t r = (q & 1u) * 64u + (uint32_t)lane;
+    const uint32_t pos = back ? wn * 32u - L.rstart[r + 1] : L.rstart[r];
+    u64 acc = 0;              // the string so far, its newest bits lowest
+    uint32_t ab = pos & 31u;  // bits not yet written, with those in front of the string's start
+    int idx = back ? (int)wn - 1 - (int)(pos >> 5) : (int)(pos >> 5);
+    auto put = [&](const uint32_t w) {
+        __hip_atomic_fetch_or(&glob_str[idx], back ? __builtin_bitreverse32(w) : w, __ATOMIC_RELAXED,
+                              __HIP_MEMORY_SCOPE_AGENT);
+        idx += back ? -1 : 1;
+    };
+#pragma unroll 1
+    for (uint32_t rr = 0; rr < 8; ++rr) {
+        const uint32_t i0 = ((q * 8u + rr) * 64u + (uint32_t)lane) * 8u;
+#pragma unroll 1
+        for (uint32_t j = 0; j < 8; ++j) {
+            if (i0 + j >= nvalid) break;
+            const uint32_t sym =
+                LAYOUT == HF_LAYOUT_BF16_EXP
+                    ? ((uint32_t)reinterpret_cast<const uint16_t*>(chunk_in)[i0 + j] >> 7) & 0xFFu
+                    : (uint32_t)reinterpret_cast<const uint8_t*>(chunk_in)[i0 + j];
+            const uint32_t e = L.enc[sym];
+            const uint32_t cl = e >> 16;
+            acc = (acc << cl) | (u64)(e & 0xFFFFu);
+            ab += cl;
+            if (ab >= 32u) {
+                ab -= 32u;
+                put((uint32_t)(acc >> ab));
+            }
+        }
+    }
+    if (ab != 0u) put((uint32_t)(acc << (32u - ab)));
+    page_copy_out(L, payload, off0, hdr_words);
+}
+
+template <int LAYOUT, bool FULL>
+__device__ __forceinline__ void encode_page_placed_late(
+    EncPageLds& L, const void* chunk_in, uint8_t* side_chunk, const uint32_t* __restrict__ enc_tab,
+    const uint32_t nvalid, uint32_t* __restrict__ payload, u64* desc, const uint32_t c,
+    const uint32_t nchunks, const u64 limit, uint32_t* __restrict__ page_off, uint32_t* err) {
+    const int lane = hf_lane();
+    const uint32_t tid = threadIdx.x;
+    const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t tab = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(L.enc));
+    constexpr uint32_t hdr_words = 1u + kGap;
+    constexpr uint32_t kHdrPieces = (hdr_words + 3u) / 4u;  // 16-byte pieces cleared up front
+
+    uint32_t sy[16];
+    load_string<LAYOUT, FULL>(chunk_in, side_chunk, q, lane, nvalid, sy);
+    L.enc[tid] = enc_tab[tid];
+    // the header word and the region lengths are OR-ed into; the strings area is cleared below,
+    // once its size is known
+    if (tid < kHdrPieces) reinterpret_cast<uint4*>(L.img)[tid] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+
+    uint32_t comb[32], clp[8];
+    L.tlen[tid] = join_string<FULL>(sy, q, lane, nvalid, tab, comb, clp);
+    __syncthreads();
+
+    if (q < 2) {
+        // region lengths, their prefix sum, the length table (as in encode_page)
+        uint32_t* const gap = L.img + 1;
+        const uint32_t R = L.tlen[tid] + L.tlen[tid + 128];
+        uint32_t incl = R;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (q == 1) incl += hf_wave_sum_u32(L.tlen[lane] + L.tlen[lane + 128]);
+        L.rstart[tid] = incl - R;
+        const uint32_t bit = 12u * tid, sh = bit & 31u;
+        __hip_atomic_fetch_or(&gap[bit >> 5], R << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (sh > 20u)
+            __hip_atomic_fetch_or(&gap[(bit >> 5) + 1], R >> (32u - sh), __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (tid == 127) {
+            L.rstart[128] = incl;
+            L.img[0] = (incl << 10) | kSharedFlag;
+            // this page's size, for the pages behind it (page 0 is its own prefix)
+            const u64 w = (u64)page_words_shared(incl);
+            __hip_atomic_store(&desc[c], (c == 0 ? kPgPrefix : kPgAggregate) | w, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+        // wavefronts 2 and 3 add up the page's bits themselves and clear the strings area
+        const uint32_t B2 = hf_wave_sum_u32(L.tlen[lane] + L.tlen[lane + 64] + L.tlen[lane + 128] +
+                                            L.tlen[lane + 192]);
+        const uint32_t w2 = page_words_shared(B2);
+        if (w2 <= (uint32_t)kImgWords)
+            for (uint32_t k = kHdrPieces + (tid - 128u); k * 4u < w2; k += 128u)
+                reinterpret_cast<uint4*>(L.img)[k] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+
+    const uint32_t B = L.rstart[128];
+    const uint32_t words = page_words_shared(B);
+    const uint32_t wn = (B + 31u) / 32u;
+    const bool in_lds = words <= (uint32_t)kImgWords;
+
+    if (in_lds) {
+        const uint32_t r = (q & 1u) * 64u + (uint32_t)lane;
+        const uint32_t pos = q < 2 ? L.rstart[r] : wn * 32u - L.rstart[r + 1];
+        uint32_t* const img_str = L.img + hdr_words;
+        if (q < 2) emit_string<false, true>(comb, clp, pos, wn, img_str, img_str);
+        else emit_string<true, true>(comb, clp, pos, wn, img_str, img_str);
+    }
+    __syncthreads();
+    // (one walk for both kinds of page, at a point where the joined codes are no longer needed)
+    const u64 pl = page_place(L, desc, c, nchunks, limit, words, page_off, err);
+    if ((pl >> 32) == 0) return;  // (the same in every thread)
+    if (in_lds) page_copy_out(L, payload, (uint32_t)pl, words);
+    else encode_page_big<LAYOUT>(L, chunk_in, nvalid, payload, (uint32_t)pl);
+}
+
+// desc: one cleared 8-byte descriptor per page; err[1] receives the stream's total words
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void hf_k_encode_pages_once(
+    const void* __restrict__ data, const uint64_t n, const uint32_t nchunks,
+    const hf_cb_dev* __restrict__ cb, uint8_t* __restrict__ side, uint32_t* __restrict__ payload,
+    uint32_t* __restrict__ page_off, u64* desc, const u64 limit, uint32_t* err) {
+    __shared__ __attribute__((aligned(1024))) EncPageLds L;
+    const uint32_t c = blockIdx.x;
+    const size_t elem_bytes = LAYOUT == HF_LAYOUT_BF16_EXP ? 2 : 1;
+    const uint64_t first = (uint64_t)c * HF_CHUNK_SYMS;
+    const uint64_t left = n - first;
+    const uint32_t nvalid = left < HF_CHUNK_SYMS ? (uint32_t)left : HF_CHUNK_SYMS;
+    const void* chunk_in = reinterpret_cast<const uint8_t*>(data) + first * elem_bytes;
+    uint8_t* side_chunk = side ? side + first : nullptr;
+    if (nvalid == HF_CHUNK_SYMS)
+        encode_page_placed_late<LAYOUT, true>(L, chunk_in, side_chunk, cb->enc, nvalid, payload, desc, c,
+                                              nchunks, limit, page_off, err);
+    else
+        encode_page_placed_late<LAYOUT, false>(L, chunk_in, side_chunk, cb->enc, nvalid, payload, desc,
+                                               c, nchunks, limit, page_off, err);
+}
+
 // ---- decoder ---------------------------------------------------------------------------------
 
 // inclusive prefix sum over the 64 lanes of a wavefront, data-parallel-primitive moves only (no
@@ -1072,6 +1367,25 @@ void hf_launch_encode_pages(const void* d_data, uint64_t n, int layout, const hf
     else if (shared_cb) HF_LAUNCH_ENC(HF_LAYOUT_U8, true);
     else HF_LAUNCH_ENC(HF_LAYOUT_U8, false);
 #undef HF_LAUNCH_ENC
+}
+
+// Pages without records placed while they are encoded (no per-page counts): d_desc holds one
+// CLEARED 8-byte descriptor per page; the total lands in d_err[1] and in d_page_off[nchunks].
+void hf_launch_encode_pages_once(const void* d_data, uint64_t n, int layout, const hf_cb_dev* shared_cb,
+                                 uint8_t* d_side, uint32_t* d_payload, uint64_t cap_words,
+                                 uint32_t* d_page_off, unsigned long long* d_desc, uint32_t* d_err,
+                                 hipStream_t s) {
+    const uint64_t nchunks = (n + HF_CHUNK_SYMS - 1) / HF_CHUNK_SYMS;
+    if (nchunks == 0) return;
+    const u64 limit = cap_words < 0xFFFFFFFFull ? cap_words : 0xFFFFFFFFull;
+    if (layout == HF_LAYOUT_BF16_EXP)
+        hipLaunchKernelGGL(hf_k_encode_pages_once<HF_LAYOUT_BF16_EXP>, dim3((unsigned)nchunks), dim3(256),
+                           0, s, d_data, n, (uint32_t)nchunks, shared_cb, d_side, d_payload, d_page_off,
+                           d_desc, limit, d_err);
+    else
+        hipLaunchKernelGGL(hf_k_encode_pages_once<HF_LAYOUT_U8>, dim3((unsigned)nchunks), dim3(256), 0, s,
+                           d_data, n, (uint32_t)nchunks, shared_cb, (uint8_t*)nullptr, d_payload,
+                           d_page_off, d_desc, limit, d_err);
 }
 
 size_t hf_page_tab_image_bytes(void) { return sizeof(DecTabLds<11>); }

@@ -105,7 +105,7 @@ def test_per_block_pipeline_replays_from_a_captured_graph(hf, orc, slotted):
 def test_reserved_context_captures_calls_it_never_ran(hf):
     # a context whose only earlier call was a histogram of a tiny tensor: hf_ctx_reserve sizes every
     # workspace for 70 000 blocks (more than the descriptor array's first size), after which the
-    # packed, the per-block (dense and slotted) and the paged pipelines are captured cold
+    # packed, the per-block (dense and slotted) and both paged pipelines are captured cold
     pages = 70_000
     n = pages * 16384
     side = torch.cuda.Stream()
@@ -119,7 +119,7 @@ def test_reserved_context_captures_calls_it_never_ran(hf):
         stat.accumulate(t[:1000].contiguous(), freq)      # the warm-up: another call, a smaller n
     ctx.reserve(n)
     side.synchronize()
-    outs = [torch.empty(n, dtype=torch.uint8, device=DEV) for _ in range(4)]
+    outs = [torch.empty(n, dtype=torch.uint8, device=DEV) for _ in range(5)]
     cb = hf.DeviceCodebook(ctx)
     keep = []
 
@@ -129,6 +129,9 @@ def test_reserved_context_captures_calls_it_never_ran(hf):
         system.codebook(freq, hf.HF_MODE_HUFFMAN, out=cb)
         s = system.encode_with(t, cb, sync=False)
         decoder.decode(s, out=outs[0], check_stream=False)
+        keep.append(s)
+        s = system.encode_with(t, cb, sync=False, paged=True)   # pages placed while encoded
+        decoder.decode(s, out=outs[4], check_stream=False)
         keep.append(s)
         for k, kw in enumerate(({}, {"slotted": True}, {"paged": True})):
             s = system.encode_blocks(t, mode=hf.HF_MODE_HUFFMAN, sync=False, **kw)

@@ -26,17 +26,20 @@ def oracle_stream(orc, sym, mode=1, thr=0):
     return payload, off, code, lens
 
 
+# counts: the pages placed beforehand from per-page counts, or while they are encoded
+@pytest.mark.parametrize("counts", [False, True])
 @pytest.mark.parametrize("kind,n", [
     ("geom", 1), ("geom", 511), ("geom", CH), ("geom", CH + 1), ("normal", 5 * CH),
     ("mixed", 9 * CH + 77), ("uniform", 4 * CH), ("const", 3 * CH + 5), ("mixed", 300 * CH + 4097),
 ])
-def test_shared_pages_match_the_oracle(hf, orc, kind, n):
+def test_shared_pages_match_the_oracle(hf, orc, kind, n, counts):
     sym = make(kind, n, n % 1000 + 5)
     t = to_dev(sym)
     sys_ = hf.EntropyAwareHuffmanSystem()
     dec = hf.ParrallelHuffmanDecoder(ctx=sys_.ctx)
-    s = sys_.encode(t, mode=hf.HF_MODE_HUFFMAN, paged=True)
+    s = sys_.encode(t, mode=hf.HF_MODE_HUFFMAN, paged=True, page_counts=counts)
     assert s.paged and s.codebook is not None and s.chunk_codebooks is None
+    assert (s.chunk_freq is not None) == counts
     payload, off, code, lens = oracle_stream(orc, sym)
     compare(s, payload, off, f"({kind}, {n})")
     gc, gl, mode, _ = s.codebook.download()
@@ -65,13 +68,14 @@ def test_shared_pages_bypass_and_threshold(hf, orc):
         assert torch.equal(dec.decode(s), t)
 
 
-def test_shared_pages_bf16_and_decode_on_read(hf, orc):
+@pytest.mark.parametrize("counts", [False, True])
+def test_shared_pages_bf16_and_decode_on_read(hf, orc, counts):
     n = 37 * CH + 1234
     bits = gaussian_bf16(n, seed=3)
     t = to_dev(bits.view(np.int16)).view(torch.bfloat16)
     sys_ = hf.EntropyAwareHuffmanSystem()
     dec = hf.ParrallelHuffmanDecoder(ctx=sys_.ctx)
-    s = sys_.encode(t, mode=hf.HF_MODE_HUFFMAN, paged=True)
+    s = sys_.encode(t, mode=hf.HF_MODE_HUFFMAN, paged=True, page_counts=counts)
     esym, eside = orc.symbolize(bits, orc.LAYOUT_BF16_EXP)
     payload, off, _, _ = oracle_stream(orc, esym)
     compare(s, payload, off, "(bf16)")
@@ -106,11 +110,12 @@ def test_shared_pages_with_a_foreign_codebook(hf, orc):
     sym = np.concatenate([make("geom", 2 * CH, 4), np.full(CH, rare, np.uint8),
                           rng.integers(128, 256, n - 3 * CH).astype(np.uint8)])
     t = to_dev(sym)
-    s = sys_.encode_with(t, cb, paged=True)
     payload, off = orc.rp_encode_pages_shared(sym, code, lens)
     assert int(np.diff(off.astype(np.int64)).max()) == 49 + CH * int(lens[rare]) // 32 > 4224
-    compare(s, payload, off, "(foreign codebook)")
-    assert torch.equal(dec.decode(s), t)
+    for counts in (None, sys_.histogram_pages(t)[0]):
+        s = sys_.encode_with(t, cb, paged=True, chunk_freq=counts)
+        compare(s, payload, off, "(foreign codebook)")
+        assert torch.equal(dec.decode(s), t)
     out = dec.decode_blocks(s, to_dev(np.array([2, 1], np.int32)))
     assert np.array_equal(out.cpu().numpy(), np.concatenate([sym[2 * CH:3 * CH], sym[CH:2 * CH]]))
 
@@ -207,7 +212,7 @@ def test_shared_pages_refusals_and_damage(hf, orc):
     sys_.ctx.flush()
     # a payload buffer that is too small is reported, nothing written behind it
     small = torch.full((s.total_words - 1 + 8,), -1, dtype=torch.int32, device=DEV)
-    freq = s.chunk_freq
+    freq = sys_.histogram_pages(t)[0]
     rc = lib.hf_encode_pages_shared(h, P(t), n, hf.HF_LAYOUT_U8, C.c_void_p(s.codebook.ptr), P(freq),
                                     None, P(small), s.total_words - 1, P(torch.empty_like(s.chunk_off)),
                                     C.byref(C.c_uint64(0)))
@@ -215,6 +220,40 @@ def test_shared_pages_refusals_and_damage(hf, orc):
     sys_.ctx.flush()
     assert lib.hf_encode_pages_shared(h, P(t), n, hf.HF_LAYOUT_U8, None, P(freq), None, P(small), 8,
                                       P(s.chunk_off), None) == L.HF_ERR_ARG
+    # placed while they are encoded, the pages in front of the one that does not fit are written,
+    # nothing behind the buffer's stated size is, and the call reports the same
+    small.fill_(-1)
+    rc = lib.hf_encode_pages_shared(h, P(t), n, hf.HF_LAYOUT_U8, C.c_void_p(s.codebook.ptr), None,
+                                    None, P(small), s.total_words - 1, P(torch.empty_like(s.chunk_off)),
+                                    C.byref(C.c_uint64(0)))
+    assert rc == L.HF_ERR_OVERFLOW and bool((small[s.total_words - 1:] == -1).all())
+    last = int(s.chunk_off[3].item())
+    assert torch.equal(small[:last], s.payload[:last]) and bool((small[last:] == -1).all())
+    sys_.ctx.flush()
+
+
+@pytest.mark.parametrize("layout", ["u8", "bf16"])
+def test_pages_placed_while_encoded_equal_pages_placed_from_counts(hf, orc, layout):
+    # many more pages than the GPU holds workgroups (the walk back over the descriptors runs through
+    # thousands of pages that finish in any order), twice on one context, the second call shorter
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    dec = hf.ParrallelHuffmanDecoder(ctx=sys_.ctx)
+    for n in (9000 * CH + 4321, 2500 * CH):
+        if layout == "bf16":
+            t = (torch.randn(n, device=DEV, generator=torch.Generator(DEV).manual_seed(n % 89)) * 0.02
+                 ).to(torch.bfloat16)
+        else:
+            g = torch.Generator(DEV).manual_seed(n % 97)
+            t = (torch.randn(n, device=DEV, generator=g) * 20 + 128).clamp(0, 255).to(torch.uint8)
+        a = sys_.encode(t, mode=hf.HF_MODE_HUFFMAN, paged=True, page_counts=True)
+        b = sys_.encode(t, mode=hf.HF_MODE_HUFFMAN, paged=True, page_counts=False)
+        assert b.chunk_freq is None and a.total_words == b.total_words
+        nch = a.nchunks
+        assert torch.equal(a.chunk_off[:nch + 1], b.chunk_off[:nch + 1])
+        assert torch.equal(a.payload[:a.total_words], b.payload[:b.total_words])
+        if a.side is not None:
+            assert torch.equal(a.side[:n], b.side[:n])
+        assert torch.equal(dec.decode(b).view(torch.uint8), t.view(torch.uint8))
 
 
 def test_shared_pages_empty_input(hf):

@@ -63,7 +63,7 @@ def main():
     side = torch.empty(n, dtype=torch.uint8, device=dev) if lay == 1 else None
     cap = pages * (CH // 4 + 256) + 64
     pay = {k: torch.empty(cap, dtype=torch.int32, device=dev)
-           for k in ("dense", "slotted", "paged", "shared", "dense1")}
+           for k in ("dense", "slotted", "paged", "shared", "dense1", "once")}
     off = {k: torch.empty(pages + 4, dtype=torch.int32, device=dev) for k in pay}
     words_s = torch.empty(pages + 4, dtype=torch.int32, device=dev)
     out = torch.empty(n, dtype=t.dtype, device=dev)
@@ -95,11 +95,17 @@ def main():
     ms["codebook (one)"] = timed(lambda: lib.hf_system_codebook_dev(h, P(freq1), 1, 0, P(cb1)))
     ms["enc dense1"] = timed(lambda: lib.hf_encode(h, P(t), n, lay, P(cb1), P(side), P(pay["dense1"]), cap, P(off["dense1"]), None))
     ms["enc shared"] = timed(lambda: lib.hf_encode_pages_shared(h, P(t), n, lay, P(cb1), P(freq), P(side), P(pay["shared"]), cap, P(off["shared"]), None))
+    # the same pages placed while they are encoded (no per-page counts)
+    ms["enc once"] = timed(lambda: lib.hf_encode_pages_shared(h, P(t), n, lay, P(cb1), None, P(side), P(pay["once"]), cap, P(off["once"]), None))
     ctx.sync()
     sb = n if lay == 1 else 0
     words = {k: int(off[k][pages].item()) & 0xFFFFFFFF for k in pay}
+    same = words["once"] == words["shared"] and torch.equal(off["once"][:pages + 1], off["shared"][:pages + 1]) \
+        and torch.equal(pay["once"][:words["once"]], pay["shared"][:words["shared"]])
+    print("pages placed while encoded equal pages placed from counts:", "ok" if same else "MISMATCH")
     stored = {"dense1": 4 * words["dense1"] + 4 * (pages + 1) + 768,
               "shared": 4 * words["shared"] + 4 * (pages + 1) + 768,
+              "once": 4 * words["once"] + 4 * (pages + 1) + 768,
               "dense": 4 * words["dense"] + 4 * (pages + 1) + 296 * pages,
               "slotted": 4 * words["slotted"] + 8 * pages + 4 + 296 * pages,
               "paged": 4 * words["paged"] + 4 * (pages + 1)}
