@@ -346,6 +346,11 @@ def test_seeded_random_pages_against_the_oracle(hf, orc):
             assert np.array_equal(so.chunk_off[: P + 1].cpu().numpy().view(np.uint32), soff)
             assert np.array_equal(so.payload[: spay.size].cpu().numpy().view(np.uint32), spay)
             assert torch.equal(hf.ParrallelHuffmanDecoder().decode(so), t)
+            # ... the same pages placed while they are encoded (no per-page counts)
+            so = sys_.encode(t, mode=mode, paged=True, page_counts=False)
+            assert so.total_words == spay.size
+            assert np.array_equal(so.chunk_off[: P + 1].cpu().numpy().view(np.uint32), soff)
+            assert np.array_equal(so.payload[: spay.size].cpu().numpy().view(np.uint32), spay)
     # HF_MODE_BEST: per page, Huffman only where it pays; the stream still round-trips
     s = sys_.encode_blocks(t, mode=hf.HF_MODE_BEST)
     for c in range(P):
