@@ -416,7 +416,7 @@ __device__ __forceinline__ void encode_page(EncPageLds& L, const void* chunk_in,
         const uint32_t k0 = g * 4u;
         if (k0 >= a0 && k0 + 4u <= a0 + ncopy) {
             const uint4 v = reinterpret_cast<const uint4*>(L.img)[g];
-            __builtin_nontemporal_store(hf_u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<hf_u32x4*>(dst + k0));
+            *reinterpret_cast<uint4*>(dst + k0) = v;
         } else {
 #pragma unroll
             for (uint32_t i = 0; i < 4; ++i)
