@@ -135,7 +135,8 @@ trait HuffHip extends Library {
   def hf_decode_pages(ctx: Pointer, dPayload: Pointer, payloadWords: Long, dPageOff: Pointer,
                       dSide: Pointer, n: Long, layout: Int, dPageIds: Pointer, dOutSlots: Pointer,
                       nIds: Long, dOut: Pointer, nSlots: Long, check: Int): Int
-  // the same pages without records, all coded with the stream's one codebook
+  // the same pages without records, all coded with the stream's one codebook (dFreqChunks may be
+  // null: the pages are then placed while they are encoded, from one read of the data)
   def hf_encode_pages_shared(ctx: Pointer, dData: Pointer, n: Long, layout: Int, dCodebook: Pointer,
                              dFreqChunks: Pointer, dSide: Pointer, dPayload: Pointer,
                              payloadCapWords: Long, dPageOff: Pointer,
