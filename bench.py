@@ -208,6 +208,13 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))
 
+    # The one JSON line must be alone on stdout, and libraries loaded below write there too (RCCL
+    # prints a five-line version block at its first communicator): file descriptor 1 points at
+    # stderr for the rest of the run, and the line goes out through a copy of the original.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from huffman_amd import api as hf
@@ -431,7 +438,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(torch, w, args.cpu_sample, code, lens, sample_words,
                                                 sample_off)
             stream_ok = line["cpu_baseline"]["gpu_pages_equal_port"]
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=json_out, flush=True)
     if use_dist:
         barrier()
         dist.destroy_process_group()
