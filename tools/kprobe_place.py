@@ -75,4 +75,14 @@ for trial in range(8):
     print(line, flush=True)
     bufs["payload"] = big[:4 * pay_words].view(torch.int32)
     del big
+# the side buffer allocated afresh, the payload buffer kept
+for trial in range(4):
+    del bufs["side"]
+    torch.cuda.empty_cache()
+    pad = torch.empty(random.randrange(1, 3000) << 20, dtype=torch.uint8, device=dev)
+    bufs["side"] = torch.empty(n, dtype=torch.uint8, device=dev)
+    del pad
+    torch.cuda.empty_cache()
+    e_, d_ = both_ms()
+    print(f"side alloc {bufs['side'].data_ptr():#x}: {e_:.2f}/{d_:.2f}", flush=True)
 ctx.sync()
