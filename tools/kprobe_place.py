@@ -68,6 +68,14 @@ for trial in range(8):
     del pad
     torch.cuda.empty_cache()
     line = f"payload alloc {big.data_ptr():#x}:"
+    # (is the range itself slow to write, or to read?  a fill of it and a sum over it)
+    tf = []
+    for k in range(4):
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record(); big.zero_(); e1.record(); big.view(torch.int32).sum(); e2.record()
+        torch.cuda.synchronize()
+        tf.append((e0.elapsed_time(e1), e1.elapsed_time(e2)))
+    line += f"  fill {min(t[0] for t in tf[1:]):.3f} sum {min(t[1] for t in tf[1:]):.3f}"
     for off in (0, 4096, 65536, 1 << 20, (2 << 20) + 8192, 32 << 20, 80 << 20):
         bufs["payload"] = big[off:off + 4 * pay_words].view(torch.int32)
         e_, d_ = both_ms()
