@@ -435,7 +435,14 @@ __global__ __launch_bounds__(256) void hf_k_encode_pages(
     __shared__ __attribute__((aligned(1024))) EncPageLds L;
     // (the pages do not fit the payload buffer, which the scan has reported: nothing is written)
     if (*total_words > limit) return;
-    const uint32_t c = blockIdx.x;
+    // Workgroup i of a launch runs on XCD i mod 8, and each XCD has an L2 of its own: every XCD
+    // takes one contiguous eighth of the pages (the grid is 8 x ceil(nchunks / 8) workgroups), so
+    // that the lines two neighbouring pages share are completed in one L2 and an XCD writes one
+    // contiguous part of the payload.  (Measured on config 2: 5.13 -> 4.80 ms; with pages dealt out
+    // round robin the decoder is the faster one, and it keeps that order.)
+    const uint32_t per_xcd = (nchunks + 7u) / 8u;
+    const uint32_t c = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (c >= nchunks) return;
     const uint32_t off0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)page_off[c]);
     const uint32_t off1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)page_off[c + 1]);
     if (off1 < off0 || (u64)off1 > limit || off1 - off0 > HF_PAGE_MAX_WORDS ||
@@ -1358,8 +1365,9 @@ void hf_launch_encode_pages(const void* d_data, uint64_t n, int layout, const hf
     const u64* d_total = d_scan_aux + (m + 1023) / 1024;
     const void* cbp = shared_cb ? static_cast<const void*>(shared_cb) : static_cast<const void*>(cbs);
     const bool wide = layout == HF_LAYOUT_BF16_EXP;
+    const unsigned grid = (unsigned)((nchunks + 7) / 8 * 8);  // (see the kernel: an eighth per XCD)
 #define HF_LAUNCH_ENC(LAY, SH)                                                                      \
-    hipLaunchKernelGGL((hf_k_encode_pages<LAY, SH>), dim3((unsigned)nchunks), dim3(256), 0, s, d_data, \
+    hipLaunchKernelGGL((hf_k_encode_pages<LAY, SH>), dim3(grid), dim3(256), 0, s, d_data,             \
                        n, (uint32_t)nchunks, cbp, wide ? d_side : (uint8_t*)nullptr, d_payload,        \
                        d_page_off, d_total, limit, d_err)
     if (wide && shared_cb) HF_LAUNCH_ENC(HF_LAYOUT_BF16_EXP, true);
