@@ -51,6 +51,28 @@ def test_shared_pages_match_the_oracle(hf, orc, kind, n, counts):
     assert list(np.diff(off.astype(np.int64))) == [49 + (b + 31) // 32 for b in bits]
 
 
+def test_every_page_count_up_to_nineteen(hf, orc):
+    """The page encoders hand every eighth of the pages to one group of workgroups (the grid is
+    rounded up to a multiple of eight): every page count from one to nineteen, below, at and above
+    one and two multiples of eight, with a ragged last page, with and without records, word for
+    word against the oracle."""
+    sys_ = hf.EntropyAwareHuffmanSystem()
+    dec = hf.ParrallelHuffmanDecoder(ctx=sys_.ctx)
+    for pages in range(1, 20):
+        n = pages * CH - (pages * 997) % CH // 2
+        sym = make("mixed", n, 40 + pages)
+        t = to_dev(sym)
+        s = sys_.encode(t, mode=hf.HF_MODE_HUFFMAN, paged=True)
+        assert s.nchunks == pages
+        payload, off, _, _ = oracle_stream(orc, sym)
+        compare(s, payload, off, f"({pages} pages without records)")
+        assert torch.equal(dec.decode(s), t)
+        s = sys_.encode_blocks(t, mode=hf.HF_MODE_HUFFMAN, paged=True)
+        payload, off, _, _ = orc.rp_encode_pages(sym, 0, 1)
+        compare(s, payload, off, f"({pages} pages with records)")
+        assert torch.equal(dec.decode(s), t)
+
+
 def test_shared_pages_bypass_and_threshold(hf, orc):
     n = 6 * CH + 321
     sym = np.concatenate([make("uniform", 2 * CH, 1), make("geom", n - 2 * CH, 2)])
